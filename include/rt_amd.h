@@ -1,0 +1,135 @@
+/* rt_amd.h - C ABI of the MI355X-native per-pixel render path.
+ *
+ * Drop-in boundary for the two free functions of the reference CPU renderer,
+ *     void load_mesh(const char*, std::vector<Triangle*>&, bool format_has_vt, Vec3f mesh_color,
+ *                    bool reflective, Vec3f offset)        (Serial/raytracer.cpp:189,220-287)
+ *     void render(const std::vector<Triangle*>&)           (Serial/raytracer.cpp:120-187)
+ * and everything below them: GridAccel build (Serial/grid.h:79-153), fast_trace
+ * (Serial/raytracer.cpp:71-118), GridAccel::Intersect (Serial/grid.h:167-231),
+ * Triangle::Intersect (Serial/geometry.h:131-177), the PPM writer (Serial/raytracer.cpp:178-185).
+ *
+ * Plain C types only. All entry points return RT_OK (0) or a negative rt_status; none of them
+ * falls back to a CPU implementation: without a usable HIP device every compute call fails with
+ * RT_ERR_NO_DEVICE / RT_ERR_HIP.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* NULL handle, bad size, bad enum */
+    RT_ERR_IO = -2,          /* cannot create / write an output file */
+    RT_ERR_OBJ = -3,         /* face index outside the vertices read so far (the reference reads out of bounds) */
+    RT_ERR_HIP = -4,         /* a HIP runtime call failed; rt_last_error() has the text */
+    RT_ERR_NO_DEVICE = -5,   /* no HIP device visible */
+    RT_ERR_NOMEM = -6
+} rt_status;
+
+enum { RT_WALK_EARLY = 0, RT_WALK_FULL = 1 };
+
+/* Opaque scene: the triangle list that load_mesh() appends to, plus its device copy and grid. */
+typedef struct rt_scene rt_scene;
+
+/* Everything render() hard-codes (Serial/raytracer.cpp:83-89,124-128; eps Serial/geometry.h:2).
+ * rt_params_default() fills in exactly those literals. */
+typedef struct rt_params {
+    int32_t width, height;            /* 512 x 512 */
+    float cam_pos[3];                 /* (3,5,3) */
+    float cam_target[3];              /* (0,0,0) */
+    float cam_up[3];                  /* (0,-1,0) */
+    float fov;                        /* 45 */
+    float light_pos[3];               /* (5,-5,2) */
+    float kd, ks, ka;                 /* 2, 5e11, 0.2 */
+    float spec_alpha;                 /* 4; only 4 is bit-pinned to the reference (pow in double) */
+    float light_intensity;            /* 255 */
+    float shadow_scale;               /* 0.1 */
+    float eps;                        /* 0.1f: shadow-ray start and the use_eps gate */
+    int32_t walk_mode;                /* RT_WALK_EARLY (default): the primary walk stops once the nearest hit
+                                         lies before the next voxel crossing; RT_WALK_FULL: walk to the grid
+                                         exit like the reference. Same image apart from rounding-level ties. */
+    /* Screen partition for multi-GPU runs: the frame is cut into bands of RT_BAND_ROWS rows and band b
+     * belongs to part (b % part_count). The call renders only the bands of part_index and writes them
+     * stacked (local band j = global band part_index + j*part_count) into the output buffers, which
+     * hold rt_part_rows() rows. part_count = 1 renders the whole frame. */
+    int32_t part_index, part_count;
+} rt_params;
+
+#define RT_BAND_ROWS 8
+
+/* Device-side timings (hipEvents on the render stream) and counters of the last frame. */
+typedef struct rt_frame_stats {
+    float ms_build;                   /* grid build: bounds, count, scan, scatter, sort/record emit */
+    float ms_render;                  /* render kernel incl. framebuffer writes */
+    float ms_total;                   /* first build kernel to end of render */
+    int32_t grid_n[3];
+    uint32_t n_cells, n_refs;
+    uint64_t n_triangles;
+    uint64_t primary_rays, hits, shadowed;
+} rt_frame_stats;
+
+const char* rt_last_error(void);
+const char* rt_version(void);
+
+void rt_params_default(rt_params* p);
+/* Rows held by the output buffers of a partitioned render (a multiple of RT_BAND_ROWS; == height rounded
+ * up when part_count == 1 is not used: for part_count == 1 it is exactly height). */
+int32_t rt_part_rows(const rt_params* p);
+
+/* ---- scene: replaces the std::vector<Triangle*> that load_mesh() fills ---- */
+rt_scene* rt_scene_create(void);
+void rt_scene_destroy(rt_scene* s);
+/* load_mesh (Serial/raytracer.cpp:220-287): same record handling, same double->float rounding of
+ * (coordinate + offset), 1-based face indices, triangle index = order of the f lines over all calls.
+ * A missing file adds nothing and returns 0 like the reference. Returns triangles added or <0. */
+int64_t rt_scene_add_obj(rt_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]);
+/* Same, for a mesh already in memory: n triangles, 9 floats each (v0 v1 v2). */
+int64_t rt_scene_add_triangles(rt_scene* s, const float* v9, int64_t n, const float color[3]);
+int64_t rt_scene_num_triangles(const rt_scene* s);
+/* Copies the host triangle list out (9 floats per triangle). */
+int rt_scene_get_triangles(const rt_scene* s, float* v9);
+
+/* Uploads the triangle list to the current HIP device as SoA float4 arrays (the scene upload of
+ * render()'s caller side; replaces the per-Triangle heap objects of Serial/raytracer.cpp:273-282). */
+int rt_scene_upload(rt_scene* s);
+/* GridAccel::GridAccel (Serial/grid.h:79-153) on the GPU: bounds, resolution, count, prefix scan,
+ * scatter, per-cell ascending order. Runs asynchronously on `stream` (a hipStream_t, may be NULL). */
+int rt_scene_build_grid(rt_scene* s, void* stream);
+/* Grid read-back for verification: n[3], lo/hi[6], width[3], inv_width[3]. */
+int rt_scene_get_grid(rt_scene* s, int32_t n[3], float lohi[6], float width[3], float inv_width[3], uint32_t* n_cells, uint32_t* n_refs);
+/* CSR read-back: cell_start[n_cells+1], cell_tris[n_refs] (ascending triangle index inside each cell). */
+int rt_scene_get_csr(rt_scene* s, uint32_t* cell_start, uint32_t* cell_tris);
+
+/* ---- render(): Serial/raytracer.cpp:120-187 ---- */
+/* Device-resident variant: grid build (unless already built for this triangle list and rebuild == 0),
+ * render kernel and framebuffer writes, all asynchronous on `stream`. Any of the three device
+ * pointers may be NULL. d_rgb_f32: 3 floats per pixel (the Vec3f image of :141), d_rgb_u8: the PPM
+ * body bytes of :181-183, d_hit_id: primary-hit triangle index or -1. Row-major, rt_part_rows() rows. */
+int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_grid, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id, void* stream);
+/* Host-buffer variant (uploads if needed, renders, copies back, synchronises). Buffers may be NULL. */
+int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id);
+/* render() including its file output: writes "P6\nW H\n255\n" + body to `path` ("./test.ppm" in the reference). */
+int rt_render_ppm(rt_scene* s, const rt_params* p, const char* path);
+/* Stats of the last rt_render_device()/rt_render() on this scene; synchronises on its events. */
+int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out);
+
+/* Band de-interleave after a gather: src holds part_count stacked partial frames of rt_part_rows() rows
+ * each (rank-major), dst is the full row-major frame. elem_bytes = bytes per pixel (12, 3 or 4). */
+int rt_deinterleave_device(const rt_params* p, const void* d_src, void* d_dst, int32_t elem_bytes, void* stream);
+
+/* PPM writer of Serial/raytracer.cpp:178-185 from a float image. */
+int rt_write_ppm(const char* path, const float* rgb, int32_t w, int32_t h);
+/* Same from already quantised bytes. */
+int rt_write_ppm_u8(const char* path, const uint8_t* rgb, int32_t w, int32_t h);
+
+/* Counterpart of plane_mesh_creator.py:23-80 (the y = -1 plane from -5 to +5.1, two triangles per
+ * square): writes the same OBJ text for a given SQUARES_PER_UNIT (a power of ten). */
+int rt_make_plane_obj(const char* path, int32_t squares_per_unit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

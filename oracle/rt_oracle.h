@@ -1,0 +1,68 @@
+/* TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement, in plain C, of the reference's per-pixel render path
+ * (Serial/raytracer.cpp, Serial/geometry.h, Serial/grid.h). It is the parity checker for the
+ * HIP path and the "port" CPU baseline of bench.py. Nothing in the product path (the library
+ * built from ray-tracer_amd/csrc) includes, links or calls this file.
+ *
+ * Parity pinning: the restatement is checked bit-for-bit (hit ids, float colours, grid CSR,
+ * loaded vertices) against the reference compiled from its own sources (oracle/_ref, built by
+ * oracle/Makefile) in tests/test_oracle_vs_ref.py, and against the golden fixtures under
+ * tests/golden/ that were generated from that same compiled reference.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rto_scene rto_scene;
+
+/* Defaults are the literals of Serial/raytracer.cpp:83-89,124-128 and Serial/geometry.h:2. */
+typedef struct rto_params {
+    int32_t width, height;
+    float cam_pos[3], cam_target[3], cam_up[3];
+    float fov;
+    float light_pos[3];
+    float kd, ks, ka, spec_alpha, light_intensity, shadow_scale, eps;
+    int32_t walk_mode;   /* 0 = full walk to the grid exit (what the reference executes);
+                            1 = early exit (primary: stop once the nearest hit lies before the
+                                next voxel crossing; shadow: stop at the first passing triangle) */
+    float early_slack;   /* relative slack on the early-exit comparison */
+} rto_params;
+
+typedef struct rto_counters {
+    uint64_t primary_rays, primary_entering, hits, shadow_rays, shadow_entering, shadowed;
+    uint64_t steps_primary, tests_primary, steps_shadow, tests_shadow;
+} rto_counters;
+
+void rto_params_default(rto_params* p);
+
+rto_scene* rto_scene_create(void);
+void rto_scene_destroy(rto_scene* s);
+/* Restates load_mesh (Serial/raytracer.cpp:220-287). Returns triangles added, or <0 on a bad face index. */
+int64_t rto_scene_add_obj(rto_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]);
+/* Adds n triangles given as 9 floats each (v0,v1,v2) with one colour. */
+int64_t rto_scene_add_triangles(rto_scene* s, const float* v9, int64_t n, const float color[3]);
+int64_t rto_scene_num_triangles(const rto_scene* s);
+const float* rto_scene_triangles(const rto_scene* s);
+
+/* Restates GridAccel::GridAccel (Serial/grid.h:79-153) into CSR form. Returns wall ms. */
+double rto_scene_build_grid(rto_scene* s);
+void rto_grid_info(const rto_scene* s, int32_t n[3], float lohi[6], float width[3], float inv_width[3]);
+int64_t rto_grid_csr(const rto_scene* s, const uint32_t** cell_start, const uint32_t** cell_tris);
+
+/* Renders rows [y0,y1) of the frame: rgb (3 floats per pixel) and ids (primary-hit triangle or -1),
+ * either may be NULL. counters (may be NULL) are ADDED to. Returns wall ms of the pixel loop. */
+double rto_render_rows(const rto_scene* s, const rto_params* p, int y0, int y1, float* rgb, int32_t* ids, rto_counters* counters);
+
+/* The PPM quantisation of Serial/raytracer.cpp:181-183. */
+void rto_quantize(const float* c, int64_t n, unsigned char* out);
+/* Writes "P6\nW H\n255\n" + quantised body (Serial/raytracer.cpp:178-185). Returns 0 on success. */
+int rto_write_ppm(const char* path, const float* rgb, int w, int h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,234 @@
+"""Python host-side mirror of the reference's load_mesh()/render() interface, bound to the C ABI of
+include/rt_amd.h (librt_amd.so, hand-written HIP for gfx950). This module is plumbing for tests and the
+benchmark driver: it contains no rendering code and has no CPU fallback. If the shared library is missing
+the import fails; if no HIP device is visible every compute call raises RtError.
+
+The directory name contains a hyphen, so import it with
+    rt = importlib.import_module("ray-tracer_amd")
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+
+RT_WALK_EARLY, RT_WALK_FULL = 0, 1
+RT_BAND_ROWS = 8
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """rt_params of include/rt_amd.h; the defaults are the literals of Serial/raytracer.cpp:83-89,124-128."""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("cam_pos", C.c_float * 3), ("cam_target", C.c_float * 3), ("cam_up", C.c_float * 3),
+        ("fov", C.c_float),
+        ("light_pos", C.c_float * 3),
+        ("kd", C.c_float), ("ks", C.c_float), ("ka", C.c_float),
+        ("spec_alpha", C.c_float), ("light_intensity", C.c_float), ("shadow_scale", C.c_float), ("eps", C.c_float),
+        ("walk_mode", C.c_int32),
+        ("part_index", C.c_int32), ("part_count", C.c_int32),
+    ]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [
+        ("ms_build", C.c_float), ("ms_render", C.c_float), ("ms_total", C.c_float),
+        ("grid_n", C.c_int32 * 3), ("n_cells", C.c_uint32), ("n_refs", C.c_uint32),
+        ("n_triangles", C.c_uint64), ("primary_rays", C.c_uint64), ("hits", C.c_uint64), ("shadowed", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        d = {}
+        for n, _ in self._fields_:
+            v = getattr(self, n)
+            d[n] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+# every symbol include/rt_amd.h declares
+EXPORTS = [
+    "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_num_triangles",
+    "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
+    "rt_render_device", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_deinterleave_device",
+    "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads librt_amd.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(f"{LIB_PATH} is missing: build it with `make -C ray-tracer_amd/csrc` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_uint32)
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_version.restype = C.c_char_p
+    L.rt_params_default.argtypes = [vp]
+    L.rt_part_rows.argtypes = [vp]
+    L.rt_part_rows.restype = i32
+    L.rt_scene_create.restype = vp
+    L.rt_scene_destroy.argtypes = [vp]
+    L.rt_scene_add_obj.argtypes = [vp, C.c_char_p, C.c_int, vp, vp]
+    L.rt_scene_add_obj.restype = i64
+    L.rt_scene_add_triangles.argtypes = [vp, vp, i64, vp]
+    L.rt_scene_add_triangles.restype = i64
+    L.rt_scene_num_triangles.argtypes = [vp]
+    L.rt_scene_num_triangles.restype = i64
+    L.rt_scene_get_triangles.argtypes = [vp, vp]
+    L.rt_scene_upload.argtypes = [vp]
+    L.rt_scene_build_grid.argtypes = [vp, vp]
+    L.rt_scene_get_grid.argtypes = [vp, vp, vp, vp, vp, u32p, u32p]
+    L.rt_scene_get_csr.argtypes = [vp, vp, vp]
+    L.rt_render_device.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+    L.rt_render.argtypes = [vp, vp, vp, vp, vp]
+    L.rt_render_ppm.argtypes = [vp, vp, C.c_char_p]
+    L.rt_scene_last_stats.argtypes = [vp, vp]
+    L.rt_deinterleave_device.argtypes = [vp, vp, vp, i32, vp]
+    L.rt_write_ppm.argtypes = [C.c_char_p, vp, i32, i32]
+    L.rt_write_ppm_u8.argtypes = [C.c_char_p, vp, i32, i32]
+    L.rt_make_plane_obj.argtypes = [C.c_char_p, i32]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise RtError(f"rt_amd error {rc}: {lib().rt_last_error().decode(errors='replace')}")
+    return rc
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def default_params(width=512, height=512, **kw):
+    p = Params()
+    lib().rt_params_default(C.byref(p))
+    p.width, p.height = width, height
+    for k, v in kw.items():
+        setattr(p, k, _f3(v) if isinstance(v, (tuple, list)) else v)
+    return p
+
+
+def part_rows(p):
+    return lib().rt_part_rows(C.byref(p))
+
+
+class Scene:
+    """The triangle list load_mesh() appends to (Serial/raytracer.cpp:193-196) and render() consumes."""
+
+    def __init__(self):
+        self.h = C.c_void_p(lib().rt_scene_create())
+        if not self.h:
+            raise RtError("rt_scene_create failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # load_mesh(filename, triangle_list, format_has_vt, mesh_color, reflective=false, offset=(0,0,0))
+    def load_mesh(self, filename, format_has_vt=True, mesh_color=(255, 0, 0), offset=(0, 0, 0)):
+        return _check(lib().rt_scene_add_obj(self.h, os.fsencode(filename), int(format_has_vt), _f3(mesh_color), _f3(offset)))
+
+    def add_triangles(self, v9, mesh_color=(255, 0, 0)):
+        v9 = np.ascontiguousarray(v9, dtype=np.float32).reshape(-1, 9)
+        return _check(lib().rt_scene_add_triangles(self.h, v9.ctypes.data, v9.shape[0], _f3(mesh_color)))
+
+    @property
+    def num_triangles(self):
+        return lib().rt_scene_num_triangles(self.h)
+
+    def triangles(self):
+        out = np.empty((self.num_triangles, 9), np.float32)
+        if out.size:
+            _check(lib().rt_scene_get_triangles(self.h, out.ctypes.data))
+        return out
+
+    def upload(self):
+        _check(lib().rt_scene_upload(self.h))
+
+    def build_grid(self, stream=None):
+        _check(lib().rt_scene_build_grid(self.h, stream))
+
+    def grid_info(self):
+        n = (C.c_int32 * 3)()
+        lohi = (C.c_float * 6)()
+        w = (C.c_float * 3)()
+        iw = (C.c_float * 3)()
+        nc, nr = C.c_uint32(), C.c_uint32()
+        _check(lib().rt_scene_get_grid(self.h, n, lohi, w, iw, C.byref(nc), C.byref(nr)))
+        return dict(n=np.array(n[:], np.int32), lohi=np.array(lohi[:], np.float32), width=np.array(w[:], np.float32),
+                    inv_width=np.array(iw[:], np.float32), n_cells=nc.value, n_refs=nr.value)
+
+    def grid_csr(self):
+        gi = self.grid_info()
+        start = np.empty(gi["n_cells"] + 1, np.uint32)
+        tris = np.empty(max(gi["n_refs"], 1), np.uint32)
+        _check(lib().rt_scene_get_csr(self.h, start.ctypes.data, tris.ctypes.data))
+        return start, tris[:gi["n_refs"]]
+
+    # render(triangle_list): host-buffer variant
+    def render(self, params, want_rgb=True, want_u8=False, want_ids=True):
+        rows, w = part_rows(params), params.width
+        rgb = np.empty((rows, w, 3), np.float32) if want_rgb else None
+        u8 = np.empty((rows, w, 3), np.uint8) if want_u8 else None
+        ids = np.empty((rows, w), np.int32) if want_ids else None
+        _check(lib().rt_render(self.h, C.byref(params), rgb.ctypes.data if want_rgb else None,
+                               u8.ctypes.data if want_u8 else None, ids.ctypes.data if want_ids else None))
+        return rgb, u8, ids
+
+    def render_device(self, params, rebuild_grid=False, d_rgb=None, d_u8=None, d_ids=None, stream=None):
+        """Device pointers are plain integers (e.g. torch.Tensor.data_ptr())."""
+        _check(lib().rt_render_device(self.h, C.byref(params), int(rebuild_grid), d_rgb, d_u8, d_ids, stream))
+
+    def render_ppm(self, params, path):
+        _check(lib().rt_render_ppm(self.h, C.byref(params), os.fsencode(path)))
+
+    def last_stats(self):
+        st = FrameStats()
+        _check(lib().rt_scene_last_stats(self.h, C.byref(st)))
+        return st.as_dict()
+
+
+def deinterleave_device(params, d_src, d_dst, elem_bytes, stream=None):
+    _check(lib().rt_deinterleave_device(C.byref(params), d_src, d_dst, elem_bytes, stream))
+
+
+def write_ppm(path, rgb_f32):
+    rgb = np.ascontiguousarray(rgb_f32, dtype=np.float32)
+    h, w = rgb.shape[:2]
+    _check(lib().rt_write_ppm(os.fsencode(path), rgb.ctypes.data, w, h))
+
+
+def make_plane_obj(path, squares_per_unit=10):
+    _check(lib().rt_make_plane_obj(os.fsencode(path), squares_per_unit))
+
+
+def subdivide(v9, k):
+    """Midpoint subdivision of a triangle soup, k times (each triangle -> 4). The midpoint of an edge is
+    (a + b) * 0.5 in float, symmetric in a and b, so shared edges stay watertight without an index.
+    Used for the labelled stand-in of the absent nefertiti mesh."""
+    t = np.ascontiguousarray(v9, dtype=np.float32).reshape(-1, 3, 3)
+    for _ in range(k):
+        a, b, c = t[:, 0], t[:, 1], t[:, 2]
+        ab = ((a + b) * np.float32(0.5)).astype(np.float32)
+        bc = ((b + c) * np.float32(0.5)).astype(np.float32)
+        ca = ((c + a) * np.float32(0.5)).astype(np.float32)
+        t = np.stack([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1), np.stack([ca, bc, c], 1),
+                      np.stack([ab, bc, ca], 1)], 1).reshape(-1, 3, 3)
+    return np.ascontiguousarray(t.reshape(-1, 9))

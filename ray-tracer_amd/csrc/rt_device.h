@@ -1,0 +1,89 @@
+// Structures shared by the host code (rt_host.cpp) and the HIP kernels (rt_kernels.hip), and the
+// launch wrappers the host calls. Everything here is internal; the public surface is include/rt_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_MAX_AXIS_CELLS 64                       // resolution clamp of Serial/grid.h:100
+#define RT_MAX_CELLS (64 * 64 * 64)
+#define RT_SCAN_CHUNK 1024                         // cells per scan block
+#define RT_MAX_SCAN_BLOCKS (RT_MAX_CELLS / RT_SCAN_CHUNK)
+
+// Grid description, resident in device memory: k_grid_setup writes the geometry, k_scan_apply writes n_refs.
+struct RtGrid {
+    float lo[3];
+    float hi[3];
+    float width[3];
+    float inv_width[3];
+    int32_t n[3];
+    int32_t n_cells;
+    uint32_t n_refs;        // total (cell, triangle) references = cell_start[n_cells]
+    uint32_t overflow;      // set when n_refs exceeds the capacity the scatter was given
+    uint32_t pad[2];
+};
+
+// Camera basis computed on the host exactly as Serial/raytracer.cpp:130-138 does.
+struct RtCamera {
+    float pos[3], w[3], u[3], v[3];
+    float aspect, focal_distance;
+};
+
+struct RtShade {
+    float light[3];
+    float kd, ks, ka, spec_alpha, light_intensity, shadow_scale, eps;
+};
+
+struct RtFrame {
+    int32_t width, height;        // full frame
+    int32_t part_index, part_count;
+    int32_t out_rows;             // rows held by the output buffers
+    int32_t walk_full;            // 1 = walk every primary ray to the grid exit
+    float early_slack;
+};
+
+// Device pointers of one scene.
+struct RtSceneDev {
+    const float4* v0;             // xyz + mesh index (int bits) in w
+    const float4* v1;
+    const float4* v2;
+    const float* mesh_color;      // 3 floats per mesh
+    uint32_t n_tris;
+    const RtGrid* grid;
+    const uint32_t* cell_start;   // n_cells + 1
+    const uint32_t* occupancy;    // 1 bit per cell
+    const float4* recs;           // 3 float4 per reference, cell-major, ascending triangle index in a cell
+};
+
+struct RtOutputs {
+    float* rgb_f32;
+    uint8_t* rgb_u8;
+    int32_t* hit_id;
+    unsigned long long* counters; // [0] hits, [1] shadowed
+};
+
+// Build-time scratch.
+struct RtBuildDev {
+    float4* v0; float4* v1; float4* v2;
+    uint32_t n_tris;
+    float cube_root;              // 3.f * powf((float)T, 1.f/3.f), evaluated on the host (libm)
+    RtGrid* grid;
+    uint32_t* bounds_enc;         // 6 order-preserving encoded floats: lo xyz, hi xyz
+    uint32_t* cell_count;         // RT_MAX_CELLS
+    uint32_t* cell_start;         // RT_MAX_CELLS + 1
+    uint32_t* block_sums;         // RT_MAX_SCAN_BLOCKS
+    uint32_t* occupancy;          // RT_MAX_CELLS / 32
+    uint32_t* ref_tri;            // ref_cap, unsorted
+    uint32_t* ref_cell;           // ref_cap
+    float4* recs;                 // 3 * ref_cap
+    uint32_t ref_cap;
+    unsigned long long* counters;
+};
+
+// Launch wrappers (rt_kernels.hip). All asynchronous on `st`; they return the hipGetLastError() of their launches.
+hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh, RtBuildDev b, hipStream_t st);
+hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st);   // init, bounds, setup, count, scan -> grid.n_refs known
+hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st);   // scatter, per-cell order, record emit
+hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, hipStream_t st);
+hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32_t n_refs, hipStream_t st);
+hipError_t rt_launch_deinterleave(const void* src, void* dst, int32_t width, int32_t height, int32_t part_count,
+                                  int32_t part_rows, int32_t elem_bytes, hipStream_t st);

@@ -1,0 +1,592 @@
+// Host side of the MI355X render path: the scene (what load_mesh() appends to), the OBJ reader, the
+// camera set-up, device memory management, frame orchestration and the C ABI of include/rt_amd.h.
+// No CPU rendering lives here: every compute entry point launches the HIP kernels of rt_kernels.hip.
+#include "../../include/rt_amd.h"
+#include "rt_device.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return set_err(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* rt_last_error(void) { return g_err; }
+extern "C" const char* rt_version(void) { return "rt_amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// scene
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return RT_OK;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return set_err(RT_ERR_HIP, "hipFree: %s", hipGetErrorString(e)); }
+        hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return set_err(e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_HIP, "hipMalloc(%zu): %s", n * sizeof(T), hipGetErrorString(e)); }
+        cap = n;
+        return RT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct rt_scene {
+    // host triangle list: what load_mesh() builds, flattened
+    std::vector<float> tri;            // 9 floats per triangle: v0 v1 v2
+    std::vector<uint32_t> tri_mesh;    // mesh index per triangle (one per load_mesh call)
+    std::vector<float> mesh_color;     // 3 floats per mesh: Triangle::material
+    // device state
+    int device = -1;
+    bool uploaded = false;
+    bool grid_valid = false;
+    uint32_t known_refs = 0;           // reference count of the current triangle list once measured
+    bool refs_known = false;
+    DevBuf<float4> v0, v1, v2;
+    DevBuf<float> d_mesh_color;
+    DevBuf<RtGrid> d_grid;
+    DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
+    DevBuf<float4> recs;
+    DevBuf<unsigned long long> counters;
+    // outputs owned by the host-buffer entry point
+    DevBuf<float> o_rgb;
+    DevBuf<uint8_t> o_u8;
+    DevBuf<int32_t> o_id;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_recorded = false;
+    bool built_this_frame = false;
+    hipStream_t last_stream = nullptr;
+    rt_params last_params;
+};
+
+extern "C" rt_scene* rt_scene_create(void) {
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (s) memset(&s->last_params, 0, sizeof(s->last_params));
+    return s;
+}
+
+extern "C" void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    if (s->device >= 0) {
+        (void)hipSetDevice(s->device);
+        s->v0.release(); s->v1.release(); s->v2.release(); s->d_mesh_color.release(); s->d_grid.release();
+        s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
+        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->counters.release();
+        s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
+        for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    }
+    delete s;
+}
+
+static void scene_touch(rt_scene* s) { s->uploaded = false; s->grid_valid = false; s->refs_known = false; }
+
+extern "C" int64_t rt_scene_add_triangles(rt_scene* s, const float* v9, int64_t n, const float color[3]) {
+    if (!s || n < 0 || (n > 0 && !v9) || !color) return set_err(RT_ERR_INVALID, "rt_scene_add_triangles: bad argument");
+    if ((uint64_t)s->tri_mesh.size() + (uint64_t)n >= 0x7fffffffull) return set_err(RT_ERR_INVALID, "too many triangles");
+    uint32_t mesh = (uint32_t)(s->mesh_color.size() / 3);
+    s->mesh_color.insert(s->mesh_color.end(), color, color + 3);
+    s->tri.insert(s->tri.end(), v9, v9 + 9 * n);
+    s->tri_mesh.insert(s->tri_mesh.end(), (size_t)n, mesh);
+    scene_touch(s);
+    return n;
+}
+
+extern "C" int64_t rt_scene_num_triangles(const rt_scene* s) { return s ? (int64_t)s->tri_mesh.size() : 0; }
+
+extern "C" int rt_scene_get_triangles(const rt_scene* s, float* v9) {
+    if (!s || !v9) return set_err(RT_ERR_INVALID, "rt_scene_get_triangles: bad argument");
+    memcpy(v9, s->tri.data(), s->tri.size() * sizeof(float));
+    return RT_OK;
+}
+
+// ---- OBJ reader -------------------------------------------------------------------------------
+// Behaviour of load_mesh (Serial/raytracer.cpp:220-287): the first whitespace-separated token of a line
+// selects the record; "v" reads three doubles, adds the offset in double and rounds to float; "f" takes
+// the integer in front of the first '/' of each of its first three tokens as a 1-based vertex index;
+// "vt" and every other record do not reach the render path. Triangles hold copies of the positions.
+
+static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
+
+extern "C" int64_t rt_scene_add_obj(rt_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]) {
+    (void)format_has_vt;   // the texture index is parsed by the reference but never used by the path
+    if (!s || !path || !color || !offset) return set_err(RT_ERR_INVALID, "rt_scene_add_obj: bad argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return 0;   // like the reference: a missing file is an empty mesh
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)sz + 1);
+    size_t got = fread(buf.data(), 1, (size_t)sz, f);
+    fclose(f);
+    buf[got] = 0;
+
+    std::vector<float> verts;
+    verts.reserve(1 << 16);
+    const uint32_t mesh = (uint32_t)(s->mesh_color.size() / 3);
+    const size_t tri_before = s->tri_mesh.size();
+    const double off[3] = {(double)offset[0], (double)offset[1], (double)offset[2]};
+    char* p = buf.data();
+    char* const end = p + got;
+    int64_t line_no = 0;
+    while (p < end) {
+        char* nl = (char*)memchr(p, '\n', (size_t)(end - p));
+        char* le = nl ? nl : end;
+        ++line_no;
+        char saved = *le;
+        *le = 0;   // strtod must not run into the next line
+        char* q = p;
+        while (q < le && is_ws(*q)) ++q;
+        char* t = q;
+        while (t < le && !is_ws(*t)) ++t;
+        if (t - q == 1 && *q == 'v') {
+            double c[3] = {0, 0, 0};
+            char* r = t;
+            for (int k = 0; k < 3; ++k) {
+                char* e = nullptr;
+                double d = strtod(r, &e);
+                if (e == r) break;   // operator>> stores 0 and the stream stays failed
+                c[k] = d;
+                r = e;
+            }
+            verts.push_back((float)(c[0] + off[0]));
+            verts.push_back((float)(c[1] + off[1]));
+            verts.push_back((float)(c[2] + off[2]));
+        } else if (t - q == 1 && *q == 'f') {
+            long idx[3] = {0, 0, 0};
+            char* r = t;
+            for (int k = 0; k < 3; ++k) {
+                while (r < le && is_ws(*r)) ++r;
+                bool neg = false;
+                if (r < le && (*r == '+' || *r == '-')) { neg = (*r == '-'); ++r; }
+                long v = 0;
+                while (r < le && *r >= '0' && *r <= '9') { v = v * 10 + (*r - '0'); if (v > 0x7fffffff) v = 0x7fffffff; ++r; }
+                idx[k] = neg ? -v : v;
+                while (r < le && !is_ws(*r)) ++r;   // "/vt" and anything else glued to the token
+            }
+            const long nv = (long)(verts.size() / 3);
+            if (idx[0] < 1 || idx[1] < 1 || idx[2] < 1 || idx[0] > nv || idx[1] > nv || idx[2] > nv) {
+                s->tri.resize(tri_before * 9);
+                s->tri_mesh.resize(tri_before);
+                return set_err(RT_ERR_OBJ, "%s:%lld: face index outside 1..%ld", path, (long long)line_no, nv);
+            }
+            for (int k = 0; k < 3; ++k) {
+                const float* v = &verts[3 * (size_t)(idx[k] - 1)];
+                s->tri.push_back(v[0]); s->tri.push_back(v[1]); s->tri.push_back(v[2]);
+            }
+            s->tri_mesh.push_back(mesh);
+        }
+        *le = saved;
+        p = nl ? nl + 1 : end;
+    }
+    s->mesh_color.insert(s->mesh_color.end(), color, color + 3);
+    scene_touch(s);
+    return (int64_t)(s->tri_mesh.size() - tri_before);
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameters and camera
+// ------------------------------------------------------------------------------------------------
+extern "C" void rt_params_default(rt_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->width = 512; p->height = 512;
+    p->cam_pos[0] = 3; p->cam_pos[1] = 5; p->cam_pos[2] = 3;
+    p->cam_up[1] = -1;
+    p->fov = 45;
+    p->light_pos[0] = 5; p->light_pos[1] = -5; p->light_pos[2] = 2;
+    p->kd = 2.0f; p->ks = 500000000000.0f; p->ka = 0.2f;
+    p->spec_alpha = 4; p->light_intensity = 255; p->shadow_scale = 0.1f;
+    p->eps = 1e-1f;
+    p->walk_mode = RT_WALK_EARLY;
+    p->part_index = 0; p->part_count = 1;
+}
+
+extern "C" int32_t rt_part_rows(const rt_params* p) {
+    if (!p || p->height <= 0) return 0;
+    if (p->part_count <= 1) return p->height;
+    int bands = (p->height + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
+    int per = (bands + p->part_count - 1) / p->part_count;
+    return per * RT_BAND_ROWS;
+}
+
+// Vec3::normalize of the reference (Serial/geometry.h:23-30) on the host, for the camera basis.
+static void h_normalize(float v[3]) {
+    float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    if (n2 > 0) {
+        float inv = (float)(1 / sqrt((double)n2));
+        v[0] *= inv; v[1] *= inv; v[2] *= inv;
+    }
+}
+static void h_cross(const float a[3], const float b[3], float o[3]) {
+    float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+// Camera basis and focal distance, Serial/raytracer.cpp:130-138. tan() comes from the host libm, as in the reference.
+static RtCamera make_camera(const rt_params* p) {
+    RtCamera c;
+    float up[3] = {p->cam_up[0], p->cam_up[1], p->cam_up[2]};
+    h_normalize(up);
+    for (int a = 0; a < 3; ++a) { c.pos[a] = p->cam_pos[a]; c.w[a] = -(p->cam_target[a] - p->cam_pos[a]); }
+    h_normalize(c.w);
+    h_cross(up, c.w, c.u); h_normalize(c.u);
+    h_cross(c.w, c.u, c.v); h_normalize(c.v);
+    c.aspect = (float)p->width / (float)p->height;
+    c.focal_distance = (float)(1.0f / (2.0 * tan(p->fov * M_PI / (180.0 * 2.0))));
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device plumbing
+// ------------------------------------------------------------------------------------------------
+static int scene_bind_device(rt_scene* s) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return set_err(RT_ERR_NO_DEVICE, "no HIP device: %s", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (s->device >= 0 && s->device != dev) return set_err(RT_ERR_INVALID, "scene is bound to device %d, current device is %d", s->device, dev);
+    if (s->device < 0) {
+        s->device = dev;
+        for (auto& ev : s->ev) HIP_TRY(hipEventCreate(&ev));
+    }
+    return RT_OK;
+}
+
+static RtBuildDev build_args(rt_scene* s) {
+    RtBuildDev b;
+    b.v0 = s->v0.p; b.v1 = s->v1.p; b.v2 = s->v2.p;
+    b.n_tris = (uint32_t)s->tri_mesh.size();
+    b.cube_root = 3.f * powf((float)s->tri_mesh.size(), 1.f / 3.f);   // Serial/grid.h:94, host libm
+    b.grid = s->d_grid.p;
+    b.bounds_enc = s->bounds_enc.p;
+    b.cell_count = s->cell_count.p; b.cell_start = s->cell_start.p; b.block_sums = s->block_sums.p; b.occupancy = s->occupancy.p;
+    b.ref_tri = s->ref_tri.p; b.ref_cell = s->ref_cell.p; b.recs = s->recs.p;
+    b.ref_cap = (uint32_t)s->ref_tri.cap;
+    b.counters = s->counters.p;
+    return b;
+}
+
+extern "C" int rt_scene_upload(rt_scene* s) {
+    if (!s) return set_err(RT_ERR_INVALID, "rt_scene_upload: NULL scene");
+    int rc = scene_bind_device(s);
+    if (rc) return rc;
+    if (s->uploaded) return RT_OK;
+    const size_t T = s->tri_mesh.size();
+    const size_t Tn = T ? T : 1;
+    if ((rc = s->v0.ensure(Tn)) || (rc = s->v1.ensure(Tn)) || (rc = s->v2.ensure(Tn))) return rc;
+    if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
+    if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
+        (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
+        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(4)))
+        return rc;
+    HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
+    HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(s->occupancy.p, 0, (RT_MAX_CELLS / 32 + 2) * sizeof(uint32_t)));
+    if (T) {
+        // stage the 36-byte host records and the mesh indices, then split them into float4 streams on the device
+        DevBuf<float> stage;
+        DevBuf<uint32_t> stage_mesh;
+        if ((rc = stage.ensure(9 * T)) || (rc = stage_mesh.ensure(T))) { stage.release(); stage_mesh.release(); return rc; }
+        hipError_t e = hipMemcpy(stage.p, s->tri.data(), 9 * T * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(stage_mesh.p, s->tri_mesh.data(), T * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = rt_launch_upload_convert(stage.p, stage_mesh.p, build_args(s), nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        stage.release(); stage_mesh.release();
+        if (e != hipSuccess) return set_err(RT_ERR_HIP, "scene upload: %s", hipGetErrorString(e));
+    }
+    if (!s->mesh_color.empty())
+        HIP_TRY(hipMemcpy(s->d_mesh_color.p, s->mesh_color.data(), s->mesh_color.size() * sizeof(float), hipMemcpyHostToDevice));
+    s->uploaded = true;
+    s->grid_valid = false;
+    return RT_OK;
+}
+
+static int build_grid_async(rt_scene* s, hipStream_t st) {
+    int rc;
+    if (!s->refs_known) {
+        // First build of this triangle list: run count + scan, read the reference total back once and size
+        // the reference arrays from it. Later builds of the same list are fully asynchronous.
+        HIP_TRY(rt_launch_build_phase1(build_args(s), st));
+        RtGrid g;
+        HIP_TRY(hipMemcpyAsync(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        s->known_refs = g.n_refs;
+        s->refs_known = true;
+        size_t need = g.n_refs ? g.n_refs : 1;
+        if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->recs.ensure(3 * need))) return rc;
+    } else {
+        HIP_TRY(rt_launch_build_phase1(build_args(s), st));
+    }
+    HIP_TRY(rt_launch_build_phase2(build_args(s), st));
+    s->grid_valid = true;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_build_grid(rt_scene* s, void* stream) {
+    if (!s) return set_err(RT_ERR_INVALID, "rt_scene_build_grid: NULL scene");
+    int rc = rt_scene_upload(s);
+    if (rc) return rc;
+    return build_grid_async(s, (hipStream_t)stream);
+}
+
+extern "C" int rt_scene_get_grid(rt_scene* s, int32_t n[3], float lohi[6], float width[3], float inv_width[3], uint32_t* n_cells, uint32_t* n_refs) {
+    if (!s || !s->grid_valid) return set_err(RT_ERR_INVALID, "rt_scene_get_grid: grid not built");
+    HIP_TRY(hipDeviceSynchronize());
+    RtGrid g;
+    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    if (g.overflow) return set_err(RT_ERR_HIP, "grid reference capacity exceeded");
+    for (int a = 0; a < 3; ++a) {
+        if (n) n[a] = g.n[a];
+        if (lohi) { lohi[a] = g.lo[a]; lohi[3 + a] = g.hi[a]; }
+        if (width) width[a] = g.width[a];
+        if (inv_width) inv_width[a] = g.inv_width[a];
+    }
+    if (n_cells) *n_cells = (uint32_t)g.n_cells;
+    if (n_refs) *n_refs = g.n_refs;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_get_csr(rt_scene* s, uint32_t* cell_start, uint32_t* cell_tris) {
+    if (!s || !s->grid_valid) return set_err(RT_ERR_INVALID, "rt_scene_get_csr: grid not built");
+    HIP_TRY(hipDeviceSynchronize());
+    RtGrid g;
+    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    if (cell_start) HIP_TRY(hipMemcpy(cell_start, s->cell_start.p, ((size_t)g.n_cells + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cell_tris && g.n_refs) {
+        DevBuf<uint32_t> tmp;
+        int rc = tmp.ensure(g.n_refs);
+        if (rc) return rc;
+        hipError_t e = rt_launch_extract_cell_tris(s->recs.p, tmp.p, g.n_refs, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(cell_tris, tmp.p, (size_t)g.n_refs * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        tmp.release();
+        if (e != hipSuccess) return set_err(RT_ERR_HIP, "csr read-back: %s", hipGetErrorString(e));
+    }
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// render
+// ------------------------------------------------------------------------------------------------
+static int check_params(const rt_params* p) {
+    if (!p) return set_err(RT_ERR_INVALID, "NULL params");
+    if (p->width <= 0 || p->height <= 0 || p->width > 65536 || p->height > 65536) return set_err(RT_ERR_INVALID, "bad frame size %dx%d", p->width, p->height);
+    if (p->part_count < 1 || p->part_index < 0 || p->part_index >= p->part_count) return set_err(RT_ERR_INVALID, "bad partition %d/%d", p->part_index, p->part_count);
+    if (p->walk_mode != RT_WALK_EARLY && p->walk_mode != RT_WALK_FULL) return set_err(RT_ERR_INVALID, "bad walk_mode %d", p->walk_mode);
+    return RT_OK;
+}
+
+extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_grid, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id, void* stream) {
+    if (!s) return set_err(RT_ERR_INVALID, "rt_render_device: NULL scene");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if ((rc = rt_scene_upload(s))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipEventRecord(s->ev[0], st));
+    s->built_this_frame = false;
+    if (rebuild_grid || !s->grid_valid) {
+        if ((rc = build_grid_async(s, st))) return rc;
+        s->built_this_frame = true;
+    }
+    HIP_TRY(hipEventRecord(s->ev[1], st));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 4 * sizeof(unsigned long long), st));
+
+    RtSceneDev sd;
+    sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
+    sd.mesh_color = s->d_mesh_color.p;
+    sd.n_tris = (uint32_t)s->tri_mesh.size();
+    sd.grid = s->d_grid.p; sd.cell_start = s->cell_start.p; sd.occupancy = s->occupancy.p; sd.recs = s->recs.p;
+    RtShade sh;
+    for (int a = 0; a < 3; ++a) sh.light[a] = p->light_pos[a];
+    sh.kd = p->kd; sh.ks = p->ks; sh.ka = p->ka; sh.spec_alpha = p->spec_alpha;
+    sh.light_intensity = p->light_intensity; sh.shadow_scale = p->shadow_scale; sh.eps = p->eps;
+    RtFrame f;
+    f.width = p->width; f.height = p->height;
+    f.part_index = p->part_index; f.part_count = p->part_count;
+    f.out_rows = rt_part_rows(p);
+    f.walk_full = (p->walk_mode == RT_WALK_FULL);
+    f.early_slack = 0.f;
+    RtOutputs o;
+    o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
+    o.counters = s->counters.p;
+    HIP_TRY(rt_launch_render(sd, make_camera(p), sh, f, o, st));
+    HIP_TRY(hipEventRecord(s->ev[2], st));
+    s->ev_recorded = true;
+    s->last_stream = st;
+    s->last_params = *p;
+    return RT_OK;
+}
+
+extern "C" int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id) {
+    if (!s) return set_err(RT_ERR_INVALID, "rt_render: NULL scene");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if ((rc = rt_scene_upload(s))) return rc;
+    const size_t px = (size_t)p->width * (size_t)rt_part_rows(p);
+    if (rgb_f32 && (rc = s->o_rgb.ensure(3 * px))) return rc;
+    if (rgb_u8 && (rc = s->o_u8.ensure(3 * px))) return rc;
+    if (hit_id && (rc = s->o_id.ensure(px))) return rc;
+    rc = rt_render_device(s, p, 0, rgb_f32 ? s->o_rgb.p : nullptr, rgb_u8 ? s->o_u8.p : nullptr, hit_id ? s->o_id.p : nullptr, nullptr);
+    if (rc) return rc;
+    if (rgb_f32) HIP_TRY(hipMemcpy(rgb_f32, s->o_rgb.p, 3 * px * sizeof(float), hipMemcpyDeviceToHost));
+    if (rgb_u8) HIP_TRY(hipMemcpy(rgb_u8, s->o_u8.p, 3 * px, hipMemcpyDeviceToHost));
+    if (hit_id) HIP_TRY(hipMemcpy(hit_id, s->o_id.p, px * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());
+    RtGrid g;
+    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    if (g.overflow) return set_err(RT_ERR_HIP, "grid reference capacity exceeded");
+    return RT_OK;
+}
+
+extern "C" int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out) {
+    if (!s || !out) return set_err(RT_ERR_INVALID, "rt_scene_last_stats: bad argument");
+    if (!s->ev_recorded) return set_err(RT_ERR_INVALID, "no frame rendered yet");
+    memset(out, 0, sizeof(*out));
+    HIP_TRY(hipEventSynchronize(s->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&out->ms_build, s->ev[0], s->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&out->ms_render, s->ev[1], s->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&out->ms_total, s->ev[0], s->ev[2]));
+    if (!s->built_this_frame) out->ms_build = 0.f;
+    RtGrid g;
+    unsigned long long c[4];
+    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    for (int a = 0; a < 3; ++a) out->grid_n[a] = g.n[a];
+    out->n_cells = (uint32_t)g.n_cells;
+    out->n_refs = g.n_refs;
+    out->n_triangles = s->tri_mesh.size();
+    // rows of this part that lie inside the frame
+    const rt_params& p = s->last_params;
+    uint64_t rows = 0;
+    const int bands = (p.height + RT_BAND_ROWS - 1) / RT_BAND_ROWS;
+    for (int b = p.part_index; b < bands; b += p.part_count) {
+        int r0 = b * RT_BAND_ROWS, r1 = r0 + RT_BAND_ROWS;
+        if (r1 > p.height) r1 = p.height;
+        rows += (uint64_t)(r1 - r0);
+    }
+    out->primary_rays = rows * (uint64_t)p.width;
+    out->hits = c[0];
+    out->shadowed = c[1];
+    return RT_OK;
+}
+
+extern "C" int rt_deinterleave_device(const rt_params* p, const void* d_src, void* d_dst, int32_t elem_bytes, void* stream) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!d_src || !d_dst || elem_bytes <= 0) return set_err(RT_ERR_INVALID, "rt_deinterleave_device: bad argument");
+    HIP_TRY(rt_launch_deinterleave(d_src, d_dst, p->width, p->height, p->part_count, rt_part_rows(p), elem_bytes, (hipStream_t)stream));
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// image output, Serial/raytracer.cpp:178-185
+// ------------------------------------------------------------------------------------------------
+extern "C" int rt_write_ppm_u8(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return set_err(RT_ERR_INVALID, "rt_write_ppm_u8: bad argument");
+    FILE* f = fopen(path, "wb");
+    if (!f) return set_err(RT_ERR_IO, "cannot open %s for writing", path);
+    fprintf(f, "P6\n%d %d\n255\n", w, h);
+    size_t n = (size_t)w * h * 3;
+    bool ok = fwrite(rgb, 1, n, f) == n;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RT_OK : set_err(RT_ERR_IO, "short write to %s", path);
+}
+
+extern "C" int rt_write_ppm(const char* path, const float* rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return set_err(RT_ERR_INVALID, "rt_write_ppm: bad argument");
+    size_t n = (size_t)w * h * 3;
+    std::vector<uint8_t> b(n);
+    for (size_t i = 0; i < n; ++i) {
+        float q = rgb[i] / 255;
+        float m = (q < 1.f) ? q : 1.f;          // std::min(float(1), q): a NaN gives 1
+        b[i] = (uint8_t)(m * 255);
+    }
+    return rt_write_ppm_u8(path, b.data(), w, h);
+}
+
+extern "C" int rt_render_ppm(rt_scene* s, const rt_params* p, const char* path) {
+    if (!path) return set_err(RT_ERR_INVALID, "rt_render_ppm: NULL path");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (p->part_count != 1) return set_err(RT_ERR_INVALID, "rt_render_ppm renders whole frames only");
+    std::vector<uint8_t> img((size_t)p->width * p->height * 3);
+    if ((rc = rt_render(s, p, nullptr, img.data(), nullptr))) return rc;
+    return rt_write_ppm_u8(path, img.data(), p->width, p->height);
+}
+
+// ------------------------------------------------------------------------------------------------
+// plane mesh generator: same OBJ text as plane_mesh_creator.py:23-80
+// ------------------------------------------------------------------------------------------------
+// round(x, ndigits) of the generator's stepper: correctly rounded decimal rounding of the exact binary value.
+static double py_round(double x, int ndigits) {
+    char tmp[64];
+    snprintf(tmp, sizeof(tmp), "%.*f", ndigits, x);
+    return strtod(tmp, nullptr);
+}
+
+extern "C" int rt_make_plane_obj(const char* path, int32_t squares_per_unit) {
+    if (!path || squares_per_unit < 1) return set_err(RT_ERR_INVALID, "rt_make_plane_obj: bad argument");
+    const int round_amount = (int)log10((double)squares_per_unit);        // plane_mesh_creator.py:20
+    const double step = 1.0 / squares_per_unit;                           // :21
+    // float_stepper(-5 + step, 5 + step, step), :23-27, with the plane corner -5 in front (:35,39)
+    std::vector<double> sl;
+    sl.push_back(-5.0);
+    for (double v = -5.0 + step; v <= 5.0 + step;) {
+        v = py_round(v, round_amount);
+        sl.push_back(v);
+        v += step;
+    }
+    const size_t n = sl.size();          // slices per axis; (n-1)^2 squares
+    for (size_t i = 1; i < n; ++i)
+        if (!(sl[i] > sl[i - 1])) return set_err(RT_ERR_INVALID, "squares_per_unit %d does not give distinct slices", squares_per_unit);
+    FILE* f = fopen(path, "wb");
+    if (!f) return set_err(RT_ERR_IO, "cannot open %s for writing", path);
+    std::vector<char> iobuf(1 << 22);
+    setvbuf(f, iobuf.data(), _IOFBF, iobuf.size());
+    // vertices in order of first appearance over the squares (x-major, z-minor, corners A B C D), :52-58
+    std::vector<int32_t> index(n * n, -1);
+    int32_t count = 0;
+    auto touch = [&](size_t ix, size_t iz) {
+        if (index[ix * n + iz] < 0) {
+            index[ix * n + iz] = count++;
+            fprintf(f, "v %f %f %f\n", sl[ix], -1.0, sl[iz]);
+        }
+    };
+    for (size_t ix = 0; ix + 1 < n; ++ix)
+        for (size_t iz = 0; iz + 1 < n; ++iz) {
+            touch(ix, iz); touch(ix + 1, iz); touch(ix + 1, iz + 1); touch(ix, iz + 1);
+        }
+    fprintf(f, "vt 0 0\n");
+    // faces (A,C,B) and (A,D,C), :60-69, 1-based, texture index 1
+    for (size_t ix = 0; ix + 1 < n; ++ix)
+        for (size_t iz = 0; iz + 1 < n; ++iz) {
+            int a = index[ix * n + iz] + 1, b = index[(ix + 1) * n + iz] + 1, c = index[(ix + 1) * n + iz + 1] + 1, d = index[ix * n + iz + 1] + 1;
+            fprintf(f, "f %d/1 %d/1 %d/1\n", a, c, b);
+            fprintf(f, "f %d/1 %d/1 %d/1\n", a, d, c);
+        }
+    bool ok = !ferror(f);
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RT_OK : set_err(RT_ERR_IO, "write to %s failed", path);
+}

@@ -1,0 +1,151 @@
+"""GPU: the HIP path, called through the C ABI, against the golden vectors and the oracle.
+Bars: hit ids bit-exact; float colours within 1/255 on >= 99.9 % of pixels (measured: bit-exact)."""
+import numpy as np
+import pytest
+
+from conftest import BLUB, CASES, SPOT, bits, cam_kwargs, golden, load_case
+
+pytestmark = pytest.mark.gpu
+
+COLOUR_TOL = 1.0 / 255.0          # on the 0..255 colour scale of the reference: one quantisation step = 1.0
+MIN_AGREE = 0.999
+
+
+def _scene(rt, name, plane10):
+    s = rt.Scene()
+    W, H, cam = load_case(lambda p, vt, c, o: s.load_mesh(p, vt, c, o), name, plane10)
+    return s, W, H, cam
+
+
+def check_image(rgb, ids, g_rgb, g_ids, exact=True):
+    assert ids.shape == g_ids.shape and rgb.shape == g_rgb.shape
+    n_id = int((ids != g_ids).sum())
+    diff = np.abs(rgb.astype(np.float64) - g_rgb.astype(np.float64)).max(axis=-1)
+    diff = np.where(np.isnan(diff), np.inf, diff)
+    agree = float((diff <= 255.0 * COLOUR_TOL).mean())
+    assert agree >= MIN_AGREE, f"only {agree:.6f} of pixels within tolerance"
+    if exact:
+        assert n_id == 0, f"{n_id} hit ids differ"
+        assert np.array_equal(bits(rgb), bits(g_rgb)), f"{int((bits(rgb) != bits(g_rgb)).any(axis=-1).sum())} pixels differ in float bits"
+    return n_id, agree
+
+
+@pytest.mark.parametrize("mode", ["early", "full"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden(rt, plane10, name, mode):
+    s, W, H, cam = _scene(rt, name, plane10)
+    p = rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL if mode == "full" else rt.RT_WALK_EARLY, **cam_kwargs(cam))
+    rgb, u8, ids = s.render(p, want_u8=True)
+    g_ids, g_rgb = golden(name)
+    check_image(rgb, ids, g_rgb, g_ids)
+    st = s.last_stats()
+    assert st["hits"] == int((g_ids >= 0).sum())
+    assert st["primary_rays"] == W * H
+
+
+@pytest.mark.parametrize("name", ["spot_640x480", "main_512x512", "plane10_480x270"])
+def test_grid_build_matches_oracle(rt, O, plane10, name):
+    s, W, H, cam = _scene(rt, name, plane10)
+    o = O.OracleScene()
+    load_case(lambda p, vt, c, off: o.add_obj(p, vt, c, off), name, plane10)
+    o.build_grid()
+    s.build_grid()
+    g, go = s.grid_info(), o.grid_info()
+    assert np.array_equal(g["n"], go["n"])
+    for k in ("lohi", "width", "inv_width"):
+        assert np.array_equal(bits(g[k]), bits(go[k])), k
+    start, tris = s.grid_csr()
+    ostart, otris = o.grid_csr()
+    assert np.array_equal(start, ostart)
+    assert np.array_equal(tris, otris)          # ascending triangle index inside every cell
+    # rebuilding gives the same lists (the scatter is atomic, the order is restored afterwards)
+    s.build_grid()
+    start2, tris2 = s.grid_csr()
+    assert np.array_equal(start, start2) and np.array_equal(tris, tris2)
+
+
+def test_u8_output_is_the_ppm_quantisation(rt, O, plane10):
+    s, W, H, cam = _scene(rt, "two_colors_200x150", plane10)
+    rgb, u8, _ = s.render(rt.default_params(W, H, **cam_kwargs(cam)), want_u8=True)
+    assert np.array_equal(u8, O.quantize(rgb))
+
+
+@pytest.mark.parametrize("W,H", [(1920, 1080), (1, 1), (7, 3), (65, 129)])
+def test_spot_sizes_against_oracle(rt, O, W, H):
+    s = rt.Scene(); s.load_mesh(SPOT)
+    o = O.OracleScene(); o.add_obj(SPOT)
+    for mode in (rt.RT_WALK_EARLY, rt.RT_WALK_FULL):
+        rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=mode))
+        o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0))
+        check_image(rgb, ids, o_rgb, o_ids)
+
+
+def test_main_scene_1024_against_oracle(rt, O):
+    s = rt.Scene(); s.load_mesh(SPOT); s.load_mesh(BLUB, True, (255, 0, 0), (1.5, 0, 0))
+    o = O.OracleScene(); o.add_obj(SPOT); o.add_obj(BLUB, True, (255, 0, 0), (1.5, 0, 0))
+    o_rgb, o_ids, _ = o.render(O.default_params(1024, 1024, walk_mode=0))
+    rgb, _, ids = s.render(rt.default_params(1024, 1024, walk_mode=rt.RT_WALK_FULL))
+    check_image(rgb, ids, o_rgb, o_ids)
+    # early exit: documented rounding-level ties may move single pixels; the bar still holds
+    rgb, _, ids = s.render(rt.default_params(1024, 1024, walk_mode=rt.RT_WALK_EARLY))
+    n_id, agree = check_image(rgb, ids, o_rgb, o_ids, exact=False)
+    assert n_id <= 4
+
+
+def test_empty_and_missing_mesh(rt):
+    s = rt.Scene()
+    assert s.load_mesh("/nonexistent.obj") == 0
+    rgb, u8, ids = s.render(rt.default_params(33, 17), want_u8=True)
+    assert (ids == -1).all() and (rgb == 0).all() and (u8 == 0).all()
+
+
+def test_single_triangle_and_degenerate_triangles(rt, O):
+    tri = np.array([[0, -1, 0, 1, -1, 0, 0, -1, 1],       # in front of the default camera
+                    [0, 0, 0, 0, 0, 0, 0, 0, 0],          # degenerate: a point
+                    [0, 0, 0, 1, 1, 1, 2, 2, 2]], np.float32)   # degenerate: a line
+    s = rt.Scene(); s.add_triangles(tri, (0, 255, 0))
+    o = O.OracleScene(); o.add_triangles(tri, (0, 255, 0))
+    p = rt.default_params(160, 120)
+    rgb, _, ids = s.render(p)
+    o_rgb, o_ids, _ = o.render(O.default_params(160, 120))
+    check_image(rgb, ids, o_rgb, o_ids)
+
+
+def test_partitioned_render_and_deinterleave(rt, plane10):
+    import torch
+    s, W, H, cam = _scene(rt, "main_odd_333x217", plane10)
+    g_ids, g_rgb = golden("main_odd_333x217")
+    for parts in (2, 3, 8):
+        pr = None
+        stacked_ids, stacked_rgb = [], []
+        for k in range(parts):
+            p = rt.default_params(W, H, part_index=k, part_count=parts, **cam_kwargs(cam))
+            pr = rt.part_rows(p)
+            rgb, _, ids = s.render(p)
+            assert ids.shape == (pr, W)
+            stacked_ids.append(ids); stacked_rgb.append(rgb)
+        src_ids = torch.from_numpy(np.concatenate(stacked_ids)).cuda()
+        src_rgb = torch.from_numpy(np.concatenate(stacked_rgb)).cuda()
+        dst_ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
+        dst_rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        p = rt.default_params(W, H, part_count=parts)
+        rt.deinterleave_device(p, src_ids.data_ptr(), dst_ids.data_ptr(), 4)
+        rt.deinterleave_device(p, src_rgb.data_ptr(), dst_rgb.data_ptr(), 12)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst_ids.cpu().numpy(), g_ids)
+        assert np.array_equal(bits(dst_rgb.cpu().numpy()), bits(g_rgb))
+
+
+def test_device_pointer_entry_point_with_rebuild(rt, plane10):
+    import torch
+    s, W, H, cam = _scene(rt, "spot_640x480", plane10)
+    g_ids, g_rgb = golden("spot_640x480")
+    p = rt.default_params(W, H, **cam_kwargs(cam))
+    ids = torch.full((H, W), -7, dtype=torch.int32, device="cuda")
+    u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(3):                      # the grid is rebuilt on the GPU every frame
+        s.render_device(p, rebuild_grid=True, d_u8=u8.data_ptr(), d_ids=ids.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(ids.cpu().numpy(), g_ids)
+    st = s.last_stats()
+    assert st["ms_build"] > 0 and st["ms_render"] > 0 and st["n_refs"] == 54252 and st["grid_n"] == [30, 54, 55]
