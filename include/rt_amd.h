@@ -59,6 +59,7 @@ typedef struct rt_params {
 } rt_params;
 
 #define RT_BAND_ROWS 8
+#define RT_STATS_RING 128
 
 /* Device-side timings (hipEvents on the render stream) and counters of the last frame. */
 typedef struct rt_frame_stats {
@@ -69,14 +70,17 @@ typedef struct rt_frame_stats {
     uint32_t n_cells, n_refs;
     uint64_t n_triangles;
     uint64_t primary_rays, hits, shadowed;
+    /* filled only while rt_scene_set_counting(s, 1) is in effect (the counting kernel is slower): */
+    uint64_t primary_entering, steps_primary, tests_primary;   /* rays that enter the grid, voxels visited, triangle tests */
+    uint64_t shadow_entering, steps_shadow, tests_shadow;
 } rt_frame_stats;
 
 const char* rt_last_error(void);
 const char* rt_version(void);
 
 void rt_params_default(rt_params* p);
-/* Rows held by the output buffers of a partitioned render (a multiple of RT_BAND_ROWS; == height rounded
- * up when part_count == 1 is not used: for part_count == 1 it is exactly height). */
+/* Rows held by the output buffers: height when part_count == 1, otherwise RT_BAND_ROWS times the bands
+ * of the largest part (the same for every part, so that a gather can use equal counts). */
 int32_t rt_part_rows(const rt_params* p);
 
 /* ---- scene: replaces the std::vector<Triangle*> that load_mesh() fills ---- */
@@ -115,6 +119,12 @@ int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, 
 int rt_render_ppm(rt_scene* s, const rt_params* p, const char* path);
 /* Stats of the last rt_render_device()/rt_render() on this scene; synchronises on its events. */
 int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out);
+/* Timings of the frame rendered `frames_back` frames before the last one (0 = last; a ring of RT_STATS_RING
+ * frames is kept, so a benchmark can time a whole run without synchronising inside it). Counters are
+ * those of the last frame. */
+int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stats* out);
+/* Work accounting: when enabled, frames also count voxel steps and triangle tests per ray class. */
+int rt_scene_set_counting(rt_scene* s, int32_t enable);
 
 /* Band de-interleave after a gather: src holds part_count stacked partial frames of rt_part_rows() rows
  * each (rank-major), dst is the full row-major frame. elem_bytes = bytes per pixel (12, 3 or 4). */

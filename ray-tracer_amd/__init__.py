@@ -41,6 +41,8 @@ class FrameStats(C.Structure):
         ("ms_build", C.c_float), ("ms_render", C.c_float), ("ms_total", C.c_float),
         ("grid_n", C.c_int32 * 3), ("n_cells", C.c_uint32), ("n_refs", C.c_uint32),
         ("n_triangles", C.c_uint64), ("primary_rays", C.c_uint64), ("hits", C.c_uint64), ("shadowed", C.c_uint64),
+        ("primary_entering", C.c_uint64), ("steps_primary", C.c_uint64), ("tests_primary", C.c_uint64),
+        ("shadow_entering", C.c_uint64), ("steps_shadow", C.c_uint64), ("tests_shadow", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -56,7 +58,8 @@ EXPORTS = [
     "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
-    "rt_render_device", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_deinterleave_device",
+    "rt_render_device", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting",
+    "rt_deinterleave_device",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
 
@@ -68,6 +71,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # A process must hold ONE HIP runtime. PyTorch wheels bundle their own libamdhip64.so.7; importing torch
+    # first makes the loader resolve this library's dependency on that SONAME to the copy torch already
+    # loaded, so tensors and this library share a device context. Without torch the system ROCm one is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RtError(f"{LIB_PATH} is missing: build it with `make -C ray-tracer_amd/csrc` (or __graft_entry__.build())")
     L = C.CDLL(LIB_PATH)
@@ -94,6 +104,8 @@ def lib():
     L.rt_render.argtypes = [vp, vp, vp, vp, vp]
     L.rt_render_ppm.argtypes = [vp, vp, C.c_char_p]
     L.rt_scene_last_stats.argtypes = [vp, vp]
+    L.rt_scene_stats_at.argtypes = [vp, i32, vp]
+    L.rt_scene_set_counting.argtypes = [vp, i32]
     L.rt_deinterleave_device.argtypes = [vp, vp, vp, i32, vp]
     L.rt_write_ppm.argtypes = [C.c_char_p, vp, i32, i32]
     L.rt_write_ppm_u8.argtypes = [C.c_char_p, vp, i32, i32]
@@ -203,6 +215,14 @@ class Scene:
         st = FrameStats()
         _check(lib().rt_scene_last_stats(self.h, C.byref(st)))
         return st.as_dict()
+
+    def stats_at(self, frames_back):
+        st = FrameStats()
+        _check(lib().rt_scene_stats_at(self.h, frames_back, C.byref(st)))
+        return st.as_dict()
+
+    def set_counting(self, enable):
+        _check(lib().rt_scene_set_counting(self.h, int(bool(enable))))
 
 
 def deinterleave_device(params, d_src, d_dst, elem_bytes, stream=None):

@@ -39,6 +39,7 @@ struct RtFrame {
     int32_t out_rows;             // rows held by the output buffers
     int32_t walk_full;            // 1 = walk every primary ray to the grid exit
     float early_slack;
+    int32_t count_work;           // 1 = the kernel also counts voxel steps and triangle tests
 };
 
 // Device pointers of one scene.
@@ -58,7 +59,7 @@ struct RtOutputs {
     float* rgb_f32;
     uint8_t* rgb_u8;
     int32_t* hit_id;
-    unsigned long long* counters; // [0] hits, [1] shadowed
+    unsigned long long* counters; // [0] hits, [1] shadowed, [2..4] primary entered/steps/tests, [5..7] shadow entered/steps/tests
 };
 
 // Build-time scratch.

@@ -74,9 +74,10 @@ struct rt_scene {
     DevBuf<float> o_rgb;
     DevBuf<uint8_t> o_u8;
     DevBuf<int32_t> o_id;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    bool ev_recorded = false;
-    bool built_this_frame = false;
+    hipEvent_t ev[RT_STATS_RING][3] = {};
+    bool built[RT_STATS_RING] = {};
+    uint64_t frames = 0;               // frames rendered so far; frame k uses ring slot k % RT_STATS_RING
+    bool count_work = false;
     hipStream_t last_stream = nullptr;
     rt_params last_params;
 };
@@ -95,7 +96,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
         s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->counters.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
-        for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+        for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
     }
     delete s;
 }
@@ -270,7 +271,7 @@ static int scene_bind_device(rt_scene* s) {
     if (s->device >= 0 && s->device != dev) return set_err(RT_ERR_INVALID, "scene is bound to device %d, current device is %d", s->device, dev);
     if (s->device < 0) {
         s->device = dev;
-        for (auto& ev : s->ev) HIP_TRY(hipEventCreate(&ev));
+        for (auto& slot : s->ev) for (auto& ev : slot) HIP_TRY(hipEventCreate(&ev));
     }
     return RT_OK;
 }
@@ -300,7 +301,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
-        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(4)))
+        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(8)))
         return rc;
     HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
     HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
@@ -404,14 +405,15 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     if (rc) return rc;
     if ((rc = rt_scene_upload(s))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipEventRecord(s->ev[0], st));
-    s->built_this_frame = false;
+    const int slot = (int)(s->frames % RT_STATS_RING);
+    HIP_TRY(hipEventRecord(s->ev[slot][0], st));
+    s->built[slot] = false;
     if (rebuild_grid || !s->grid_valid) {
         if ((rc = build_grid_async(s, st))) return rc;
-        s->built_this_frame = true;
+        s->built[slot] = true;
     }
-    HIP_TRY(hipEventRecord(s->ev[1], st));
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 4 * sizeof(unsigned long long), st));
+    HIP_TRY(hipEventRecord(s->ev[slot][1], st));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 8 * sizeof(unsigned long long), st));
 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
@@ -428,12 +430,13 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.out_rows = rt_part_rows(p);
     f.walk_full = (p->walk_mode == RT_WALK_FULL);
     f.early_slack = 0.f;
+    f.count_work = s->count_work ? 1 : 0;
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;
     HIP_TRY(rt_launch_render(sd, make_camera(p), sh, f, o, st));
-    HIP_TRY(hipEventRecord(s->ev[2], st));
-    s->ev_recorded = true;
+    HIP_TRY(hipEventRecord(s->ev[slot][2], st));
+    s->frames++;
     s->last_stream = st;
     s->last_params = *p;
     return RT_OK;
@@ -460,17 +463,28 @@ extern "C" int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_
     return RT_OK;
 }
 
-extern "C" int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out) {
-    if (!s || !out) return set_err(RT_ERR_INVALID, "rt_scene_last_stats: bad argument");
-    if (!s->ev_recorded) return set_err(RT_ERR_INVALID, "no frame rendered yet");
+extern "C" int rt_scene_set_counting(rt_scene* s, int32_t enable) {
+    if (!s) return set_err(RT_ERR_INVALID, "rt_scene_set_counting: NULL scene");
+    s->count_work = enable != 0;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out) { return rt_scene_stats_at(s, 0, out); }
+
+extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stats* out) {
+    if (!s || !out) return set_err(RT_ERR_INVALID, "rt_scene_stats_at: bad argument");
+    if (s->frames == 0) return set_err(RT_ERR_INVALID, "no frame rendered yet");
+    if (frames_back < 0 || frames_back >= RT_STATS_RING || (uint64_t)frames_back >= s->frames) return set_err(RT_ERR_INVALID, "frame %d is not in the stats ring", frames_back);
+    const int slot = (int)((s->frames - 1 - (uint64_t)frames_back) % RT_STATS_RING);
+    hipEvent_t* ev = s->ev[slot];
     memset(out, 0, sizeof(*out));
-    HIP_TRY(hipEventSynchronize(s->ev[2]));
-    HIP_TRY(hipEventElapsedTime(&out->ms_build, s->ev[0], s->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&out->ms_render, s->ev[1], s->ev[2]));
-    HIP_TRY(hipEventElapsedTime(&out->ms_total, s->ev[0], s->ev[2]));
-    if (!s->built_this_frame) out->ms_build = 0.f;
+    HIP_TRY(hipEventSynchronize(s->ev[(s->frames - 1) % RT_STATS_RING][2]));
+    HIP_TRY(hipEventElapsedTime(&out->ms_build, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&out->ms_render, ev[1], ev[2]));
+    HIP_TRY(hipEventElapsedTime(&out->ms_total, ev[0], ev[2]));
+    if (!s->built[slot]) out->ms_build = 0.f;
     RtGrid g;
-    unsigned long long c[4];
+    unsigned long long c[8];
     HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
     for (int a = 0; a < 3; ++a) out->grid_n[a] = g.n[a];
@@ -489,6 +503,8 @@ extern "C" int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out) {
     out->primary_rays = rows * (uint64_t)p.width;
     out->hits = c[0];
     out->shadowed = c[1];
+    out->primary_entering = c[2]; out->steps_primary = c[3]; out->tests_primary = c[4];
+    out->shadow_entering = c[5]; out->steps_shadow = c[6]; out->tests_shadow = c[7];
     return RT_OK;
 }
 

@@ -368,10 +368,14 @@ __device__ __forceinline__ bool tri_test(float4 r0, float4 r1, float4 r2, float 
 //   ANY_HIT: the shadow query. The reference ORs every voxel's result over the whole walk and ignores t,
 //   so leaving at the first passing triangle returns the same value.
 //   EARLY (primary rays): leave once the nearest hit so far lies before the next voxel crossing.
-template <bool ANY_HIT>
+struct WalkCount {           // work counters of one ray (only maintained by the counting build of the kernel)
+    uint32_t entered, steps, tests;
+};
+
+template <bool ANY_HIT, bool COUNT>
 __device__ __forceinline__ bool grid_walk(const GridU& g, const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ occupancy,
                                           const float4* __restrict__ recs, float ox, float oy, float oz, float dx, float dy, float dz,
-                                          float mint, bool use_eps, float eps, bool early, float slack, Nearest& st) {
+                                          float mint, bool use_eps, float eps, bool early, float slack, Nearest& st, WalkCount& wc) {
     const float o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
     // bounds.Inside(ray(mint)), Serial/geometry.h:287-289
     float rayT;
@@ -394,6 +398,7 @@ __device__ __forceinline__ bool grid_walk(const GridU& g, const uint32_t* __rest
         }
         rayT = t0;
     }
+    if (COUNT) wc.entered = 1;
     const float gi[3] = {ox + dx * rayT, oy + dy * rayT, oz + dz * rayT};
     float next[3], delta[3];
     int pos[3], step[3], out[3];
@@ -415,10 +420,12 @@ __device__ __forceinline__ bool grid_walk(const GridU& g, const uint32_t* __rest
     bool hit = false;
     for (;;) {
         const int c = pos[2] * nxy + pos[1] * nx + pos[0];
+        if (COUNT) ++wc.steps;
         if ((occupancy[c >> 5] >> (c & 31)) & 1u) {
             const uint32_t beg = cell_start[c], end = cell_start[c + 1];
             for (uint32_t k = beg; k < end; ++k) {
                 const float4* r = recs + 3ull * k;
+                if (COUNT) ++wc.tests;
                 if (tri_test<ANY_HIT>(r[0], r[1], r[2], ox, oy, oz, ddx, ddy, ddz, use_eps, eps, st)) {
                     if (ANY_HIT) return true;
                     hit = true;
@@ -440,6 +447,7 @@ __device__ __forceinline__ bool grid_walk(const GridU& g, const uint32_t* __rest
     return hit;
 }
 
+template <bool COUNT>
 __global__ void __launch_bounds__(RT_BLOCK_THREADS) k_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o) {
     // pixel of this lane: 4 wavefronts per block, one 8x8 tile each, tiles laid out left to right
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -465,6 +473,7 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) k_render(RtSceneDev s, RtCam
     float cr = 0.f, cg = 0.f, cb = 0.f;
     int id = -1;
     bool shadowed = false;
+    WalkCount wp = {0, 0, 0}, ws = {0, 0, 0};
     if (live && s.n_tris > 0) {
         // ray generation, Serial/raytracer.cpp:153-161; xw and yw are evaluated in double
         float dx = 0.f + (-cam.w[0]) * cam.focal_distance;
@@ -478,8 +487,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) k_render(RtSceneDev s, RtCam
 
         // fast_trace, Serial/raytracer.cpp:71-118
         Nearest st = {INFINITY, -1};
-        const bool hit = grid_walk<false>(g, s.cell_start, s.occupancy, s.recs, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f,
-                                          false, sh.eps, f.walk_full == 0, f.early_slack, st);
+        const bool hit = grid_walk<false, COUNT>(g, s.cell_start, s.occupancy, s.recs, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz,
+                                                 0.f, false, sh.eps, f.walk_full == 0, f.early_slack, st, wp);
         if (hit) {
             id = st.id;
             const float4 p0 = s.v0[id], p1 = s.v1[id], p2 = s.v2[id];
@@ -512,8 +521,8 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) k_render(RtSceneDev s, RtCam
             // shadow ray, Serial/raytracer.cpp:106-113: away from the light, starting at eps
             float sx = -(sh.light[0] - poix), sy = -(sh.light[1] - poiy), sz = -(sh.light[2] - poiz);
             normalize3(sx, sy, sz);
-            shadowed = grid_walk<true>(g, s.cell_start, s.occupancy, s.recs, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps, true,
-                                       0.f, st);
+            shadowed = grid_walk<true, COUNT>(g, s.cell_start, s.occupancy, s.recs, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
+                                              true, 0.f, st, ws);
             if (shadowed) { cr = cr * sh.shadow_scale; cg = cg * sh.shadow_scale; cb = cb * sh.shadow_scale; }
             cr = cr + colr * sh.ka; cg = cg + colg * sh.ka; cb = cb + colb * sh.ka;
         }
@@ -523,6 +532,16 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) k_render(RtSceneDev s, RtCam
         if (lane == 0) {
             if (hm) atomicAdd(&o.counters[0], (unsigned long long)__popcll(hm));
             if (sm) atomicAdd(&o.counters[1], (unsigned long long)__popcll(sm));
+        }
+        if (COUNT) {
+            uint32_t v[6] = {wp.entered, wp.steps, wp.tests, ws.entered, ws.steps, ws.tests};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                unsigned long long t = v[k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+                if (lane == 0 && t) atomicAdd(&o.counters[2 + k], t);
+            }
         }
     }
     if (x < f.width && y_local < f.out_rows) {
@@ -543,7 +562,8 @@ hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, R
     const int tiles_y = (f.out_rows + RT_TILE - 1) / RT_TILE;
     const int tiles = tiles_x * tiles_y;
     if (tiles <= 0) return hipSuccess;
-    k_render<<<(tiles + 3) / 4, RT_BLOCK_THREADS, 0, st>>>(s, cam, sh, f, o);
+    if (f.count_work) k_render<true><<<(tiles + 3) / 4, RT_BLOCK_THREADS, 0, st>>>(s, cam, sh, f, o);
+    else k_render<false><<<(tiles + 3) / 4, RT_BLOCK_THREADS, 0, st>>>(s, cam, sh, f, o);
     return hipGetLastError();
 }
 

@@ -149,3 +149,22 @@ def test_device_pointer_entry_point_with_rebuild(rt, plane10):
     assert np.array_equal(ids.cpu().numpy(), g_ids)
     st = s.last_stats()
     assert st["ms_build"] > 0 and st["ms_render"] > 0 and st["n_refs"] == 54252 and st["grid_n"] == [30, 54, 55]
+
+
+@pytest.mark.parametrize("name", ["spot_640x480", "main_512x512", "plane10_480x270"])
+def test_work_counters_match_oracle_early_exit(rt, O, plane10, name):
+    """The counting kernel's voxel steps and triangle tests are the algorithmic work of the early-exit
+    walk; the oracle's early-exit mode counts the same numbers on the CPU."""
+    s, W, H, cam = _scene(rt, name, plane10)
+    o = O.OracleScene()
+    load_case(lambda p, vt, c, off: o.add_obj(p, vt, c, off), name, plane10)
+    cnt = O.Counters()
+    o.render(O.default_params(W, H, walk_mode=1, **cam_kwargs(cam)), want_rgb=False, want_ids=False, counters=cnt)
+    want = cnt.as_dict()
+    s.set_counting(True)
+    s.render(rt.default_params(W, H, **cam_kwargs(cam)))
+    got = s.last_stats()
+    s.set_counting(False)
+    for k in ("primary_rays", "primary_entering", "hits", "shadow_entering", "shadowed", "steps_primary", "tests_primary",
+              "steps_shadow", "tests_shadow"):
+        assert got[k] == want[k], (k, got[k], want[k])
