@@ -73,6 +73,10 @@ typedef struct rt_frame_stats {
     /* filled only while rt_scene_set_counting(s, 1) is in effect (the counting kernel is slower): */
     uint64_t primary_entering, steps_primary, tests_primary;   /* rays that enter the grid, voxels visited, triangle tests */
     uint64_t shadow_entering, steps_shadow, tests_shadow;
+    /* scheduling diagnostics of the counting kernel: rounds of the wavefront walk, voxel streams and lanes
+     * served over all rounds, shader-clock cycles per traced tile (max, sum), traced tiles, most rounds in one tile */
+    uint64_t sched_rounds, sched_streams, sched_lanes /* cycles in the step phase */, tile_cycles_max, tile_cycles_sum, tiles_traced, tile_rounds_max,
+        cycles_test /* cycles in the test phase */;
 } rt_frame_stats;
 
 const char* rt_last_error(void);

@@ -62,6 +62,14 @@ struct RtOutputs {
     unsigned long long* counters; // [0] hits, [1] shadowed, [2..4] primary entered/steps/tests, [5..7] shadow entered/steps/tests
 };
 
+// Per-frame work list of the render kernels.
+struct RtRenderWork {
+    uint32_t* work;               // [0] listed tiles, [1] dequeue head; zeroed before each frame
+    uint32_t* tile_list;          // capacity = tiles of the frame
+    int32_t bitmap_words;         // LDS words reserved for the occupancy bitmap (>= ceil(n_cells / 32))
+    int32_t n_cu, blocks_per_cu;
+};
+
 // Build-time scratch.
 struct RtBuildDev {
     float4* v0; float4* v1; float4* v2;
@@ -84,7 +92,8 @@ struct RtBuildDev {
 hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh, RtBuildDev b, hipStream_t st);
 hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st);   // init, bounds, setup, count, scan -> grid.n_refs known
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st);   // scatter, per-cell order, record emit
-hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, hipStream_t st);
+hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st);
+size_t rt_trace_lds_bytes(int bitmap_words);
 hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32_t n_refs, hipStream_t st);
 hipError_t rt_launch_deinterleave(const void* src, void* dst, int32_t width, int32_t height, int32_t part_count,
                                   int32_t part_rows, int32_t elem_bytes, hipStream_t st);

@@ -69,7 +69,10 @@ struct rt_scene {
     DevBuf<RtGrid> d_grid;
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
     DevBuf<float4> recs;
-    DevBuf<unsigned long long> counters;
+    DevBuf<unsigned long long> counters;   // 16 frame counters + one 8-byte slot holding the two work-list words
+    DevBuf<uint32_t> tile_list;
+    int n_cu = 0;
+    uint32_t known_cells = 0;              // n_cells of the current triangle list once measured
     // outputs owned by the host-buffer entry point
     DevBuf<float> o_rgb;
     DevBuf<uint8_t> o_u8;
@@ -94,7 +97,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         (void)hipSetDevice(s->device);
         s->v0.release(); s->v1.release(); s->v2.release(); s->d_mesh_color.release(); s->d_grid.release();
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
-        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->counters.release();
+        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->counters.release(); s->tile_list.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
         for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
     }
@@ -271,6 +274,9 @@ static int scene_bind_device(rt_scene* s) {
     if (s->device >= 0 && s->device != dev) return set_err(RT_ERR_INVALID, "scene is bound to device %d, current device is %d", s->device, dev);
     if (s->device < 0) {
         s->device = dev;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         for (auto& slot : s->ev) for (auto& ev : slot) HIP_TRY(hipEventCreate(&ev));
     }
     return RT_OK;
@@ -301,7 +307,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
-        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(8)))
+        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(17)))
         return rc;
     HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
     HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
@@ -335,6 +341,7 @@ static int build_grid_async(rt_scene* s, hipStream_t st) {
         HIP_TRY(hipMemcpyAsync(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         s->known_refs = g.n_refs;
+        s->known_cells = (uint32_t)g.n_cells;
         s->refs_known = true;
         size_t need = g.n_refs ? g.n_refs : 1;
         if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->recs.ensure(3 * need))) return rc;
@@ -413,7 +420,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         s->built[slot] = true;
     }
     HIP_TRY(hipEventRecord(s->ev[slot][1], st));
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 8 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 17 * sizeof(unsigned long long), st));
 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
@@ -434,7 +441,23 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;
-    HIP_TRY(rt_launch_render(sd, make_camera(p), sh, f, o, st));
+    RtRenderWork wk;
+    {
+        const size_t tiles = (size_t)((p->width + 7) / 8) * (size_t)((f.out_rows + 7) / 8);
+        if ((rc = s->tile_list.ensure(tiles ? tiles : 1))) return rc;
+        wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 16);
+        wk.tile_list = s->tile_list.p;
+        // LDS for the occupancy bitmap: exact once the grid of this triangle list has been measured
+        const uint32_t cells = s->refs_known ? s->known_cells : (uint32_t)RT_MAX_CELLS;
+        wk.bitmap_words = (int32_t)((cells + 31) / 32);
+        if (wk.bitmap_words < 1) wk.bitmap_words = 1;
+        wk.n_cu = s->n_cu;
+        const size_t lds = rt_trace_lds_bytes(wk.bitmap_words);
+        int per_cu = (int)((160 * 1024) / lds);
+        wk.blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+
+    }
+    HIP_TRY(rt_launch_render(sd, make_camera(p), sh, f, o, wk, st));
     HIP_TRY(hipEventRecord(s->ev[slot][2], st));
     s->frames++;
     s->last_stream = st;
@@ -484,7 +507,7 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     HIP_TRY(hipEventElapsedTime(&out->ms_total, ev[0], ev[2]));
     if (!s->built[slot]) out->ms_build = 0.f;
     RtGrid g;
-    unsigned long long c[8];
+    unsigned long long c[16];
     HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
     for (int a = 0; a < 3; ++a) out->grid_n[a] = g.n[a];
@@ -505,6 +528,8 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     out->shadowed = c[1];
     out->primary_entering = c[2]; out->steps_primary = c[3]; out->tests_primary = c[4];
     out->shadow_entering = c[5]; out->steps_shadow = c[6]; out->tests_shadow = c[7];
+    out->sched_rounds = c[8]; out->sched_streams = c[9]; out->sched_lanes = c[10];
+    out->tile_cycles_max = c[11]; out->tile_cycles_sum = c[12]; out->tiles_traced = c[13]; out->tile_rounds_max = c[14]; out->cycles_test = c[15];
     return RT_OK;
 }
 

@@ -308,193 +308,420 @@ hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32
 
 // ------------------------------------------------------------------------------------------------
 // render: ray generation, 3D-DDA walk, ray-triangle tests, shading, shadow ray, framebuffer writes
+//
+// Two kernels per frame.
+//   k_classify  one wavefront per 8x8 pixel tile: generates the tile's rays, runs the grid-bounds test of
+//               GridAccel::Intersect, writes the background for tiles no ray of which enters the grid and
+//               appends every other tile to a work list (one atomic per listed tile).
+//   k_trace     persistent wavefronts pull tiles from that list. A wavefront walks its 64 rays through the
+//               grid together: every lane skips ahead through empty voxels on its own (occupancy bitmap in
+//               LDS), then the wavefront repeatedly picks one occupied voxel that some of its lanes have
+//               reached, stages that voxel's triangle records into LDS with coalesced loads (converting the
+//               edge vectors to double once per triangle instead of once per ray), and the lanes standing in
+//               that voxel test the staged triangles in ascending index order. Lanes that wait in another
+//               voxel are picked in a later round, so rays of one tile meet at the voxels they share.
 // ------------------------------------------------------------------------------------------------
+
+#define RT_WAVES_PER_BLOCK 4
+#define RT_MAX_BITMAP_WORDS (RT_MAX_CELLS / 32)
 
 struct GridU {               // grid description held in scalar registers
     float lo[3], hi[3], width[3], inv_width[3];
     int n[3];
 };
 
+__device__ __forceinline__ GridU load_grid(const RtGrid* gp) {
+    GridU g;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        g.lo[a] = gp->lo[a]; g.hi[a] = gp->hi[a]; g.width[a] = gp->width[a]; g.inv_width[a] = gp->inv_width[a];
+        g.n[a] = gp->n[a];
+    }
+    return g;
+}
+
 struct Nearest {             // the reference's two globals, per ray (Serial/geometry.h:10-11)
     float t;
     int id;
 };
 
-// Triangle::Intersect (Serial/geometry.h:131-177) on one 48-byte record. The four 3x3 determinants share
-// their 2x2 minors over the y,z rows; evaluating each minor once changes no bit because negating a minor
-// is exact and the t1 - t2 + t3 association is kept. P(u,v) = u.y*v.z - v.y*u.z.
+struct WalkCount {           // work counters of one ray (only maintained by the counting build of the kernel)
+    uint32_t entered, steps, tests;
+    uint32_t rounds, slots, lanes;   // per wavefront (identical in every lane): scheduling rounds, streams served, lanes served
+    uint32_t cyc_step, cyc_test;     // shader cycles spent in the two phases
+};
+
+// Primary ray of pixel (x, y), Serial/raytracer.cpp:153-161; xw and yw are evaluated in double.
+__device__ __forceinline__ void primary_ray(const RtCamera& cam, const RtFrame& f, int x, int y, float& dx, float& dy, float& dz) {
+    dx = 0.f + (-cam.w[0]) * cam.focal_distance;
+    dy = 0.f + (-cam.w[1]) * cam.focal_distance;
+    dz = 0.f + (-cam.w[2]) * cam.focal_distance;
+    const float xw = (float)((double)cam.aspect * ((double)x - (double)f.width / 2.0 + 0.5) / (double)f.width);
+    const float yw = (float)(((double)y - (double)f.height / 2.0 + 0.5) / (double)f.height);
+    dx = dx + cam.u[0] * xw; dy = dy + cam.u[1] * xw; dz = dz + cam.u[2] * xw;
+    dx = dx + cam.v[0] * yw; dy = dy + cam.v[1] * yw; dz = dz + cam.v[2] * yw;
+    normalize3(dx, dy, dz);
+}
+
+// Entry of GridAccel::Intersect, Serial/grid.h:172-175: rayT = mint when ray(mint) is inside the bounds
+// (boundingBox::Inside, Serial/geometry.h:287-289), else the slab test's t0 (boundingBox::Intersect,
+// Serial/geometry.h:291-316), else the ray misses the grid.
+__device__ __forceinline__ bool grid_entry(const GridU& g, float ox, float oy, float oz, float dx, float dy, float dz, float mint,
+                                           float& rayT) {
+    const float o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+    const float px = ox + dx * mint, py = oy + dy * mint, pz = oz + dz * mint;
+    const bool inside = px >= g.lo[0] && px <= g.hi[0] && py >= g.lo[1] && py <= g.hi[1] && pz >= g.lo[2] && pz <= g.hi[2];
+    if (inside) { rayT = mint; return true; }
+    float t0 = mint, t1 = INFINITY;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float inv = 1.f / d[i];
+        float tn = (g.lo[i] - o[i]) * inv;
+        float tf = (g.hi[i] - o[i]) * inv;
+        if (tn > tf) { float x = tn; tn = tf; tf = x; }
+        t0 = tn > t0 ? tn : t0;
+        t1 = tf < t1 ? tf : t1;
+        if (t0 > t1) ok = false;      // the reference returns here; later slabs cannot undo it
+    }
+    rayT = t0;
+    return ok;
+}
+
+// Pixel of lane `lane` in tile `tile` of this part: x, the row inside the part's buffers, the row in the frame.
+__device__ __forceinline__ void tile_pixel(const RtFrame& f, int tile, int lane, int& x, int& y_local, int& y) {
+    const int tiles_x = (f.width + RT_TILE - 1) / RT_TILE;
+    const int tx = tile % tiles_x, band = tile / tiles_x;
+    x = tx * RT_TILE + (lane & 7);
+    y_local = band * RT_TILE + (lane >> 3);
+    y = (band * f.part_count + f.part_index) * RT_TILE + (lane >> 3);
+}
+
+__device__ __forceinline__ void write_pixel(const RtFrame& f, const RtOutputs& o, int x, int y_local, float cr, float cg, float cb, int id) {
+    if (x < f.width && y_local < f.out_rows) {
+        const size_t pix = (size_t)y_local * f.width + x;
+        if (o.rgb_f32) { o.rgb_f32[3 * pix] = cr; o.rgb_f32[3 * pix + 1] = cg; o.rgb_f32[3 * pix + 2] = cb; }
+        if (o.rgb_u8) {
+            // PPM quantisation, Serial/raytracer.cpp:181-183: (unsigned char)(min(1, c/255)*255); a NaN gives 255
+            o.rgb_u8[3 * pix] = (uint8_t)(min_std(1.f, cr / 255) * 255);
+            o.rgb_u8[3 * pix + 1] = (uint8_t)(min_std(1.f, cg / 255) * 255);
+            o.rgb_u8[3 * pix + 2] = (uint8_t)(min_std(1.f, cb / 255) * 255);
+        }
+        if (o.hit_id) o.hit_id[pix] = id;
+    }
+}
+
+// work[0] = number of listed tiles, work[1] = dequeue head; both zeroed by the host before each frame.
+__global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, RtFrame f, RtOutputs o, uint32_t* work, uint32_t* tile_list,
+                                                  int n_tiles) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    int x, y_local, y;
+    tile_pixel(f, tile, lane, x, y_local, y);
+    bool enters = false;
+    if (x < f.width && y < f.height && s.n_tris > 0) {
+        const GridU g = load_grid(s.grid);
+        float dx, dy, dz, rayT;
+        primary_ray(cam, f, x, y, dx, dy, dz);
+        enters = grid_entry(g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, rayT);
+    }
+    if (__ballot(enters)) {
+        if (lane == 0) tile_list[atomicAdd(&work[0], 1u)] = (uint32_t)tile;
+    } else {
+        write_pixel(f, o, x, y_local, 0.f, 0.f, 0.f, -1);
+    }
+}
+
+// DDA state of one ray, Serial/grid.h:182-203.
+struct Dda {
+    float next[3], delta[3];
+    int pos[3];
+    int cell;
+};
+
+// One step of the walk loop, Serial/grid.h:216-227, plus the early-exit rule. Returns false when the ray is done.
+__device__ __forceinline__ bool dda_advance(Dda& w, const GridU& g, float dx, float dy, float dz, bool early_hit, float best_t, float slack) {
+    // stepAxis through the 3-bit compare table {2,1,2,1,2,2,0,0}
+    const int bits = ((w.next[0] < w.next[1]) << 2) + ((w.next[0] < w.next[2]) << 1) + (w.next[1] < w.next[2]);
+    const int ax = (0x0A66 >> (2 * bits)) & 3;
+    const float nx_t = ax == 0 ? w.next[0] : (ax == 1 ? w.next[1] : w.next[2]);
+    if (early_hit) {
+        const float lim = best_t + fabsf(best_t) * slack;
+        if (lim < nx_t) return false;
+    }
+    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    if (ax == 0) {
+        const int st = dx >= 0 ? 1 : -1, out = dx >= 0 ? g.n[0] : -1;
+        w.pos[0] += st; if (w.pos[0] == out) return false; w.next[0] += w.delta[0]; w.cell += st;
+    } else if (ax == 1) {
+        const int st = dy >= 0 ? 1 : -1, out = dy >= 0 ? g.n[1] : -1;
+        w.pos[1] += st; if (w.pos[1] == out) return false; w.next[1] += w.delta[1]; w.cell += st * nx;
+    } else {
+        const int st = dz >= 0 ? 1 : -1, out = dz >= 0 ? g.n[2] : -1;
+        w.pos[2] += st; if (w.pos[2] == out) return false; w.next[2] += w.delta[2]; w.cell += st * nxy;
+    }
+    return true;
+}
+
+__device__ __forceinline__ float bcast_f32(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+__device__ __forceinline__ double bcast_f64(double v, int src_lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, src_lane);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// One triangle record as a lane holds it during the test phase.
+struct TriRec {
+    float v0x, v0y, v0z;
+    uint32_t id;
+    double e1x, e1y, e1z;    // v0 - v1 (float subtraction, widened)
+    double e2x, e2y, e2z;    // v0 - v2
+    double m12;              // e1.y*e2.z - e2.y*e1.z
+};
+
+__device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, const float4 r2) {
+    TriRec t;
+    t.v0x = r0.x; t.v0y = r0.y; t.v0z = r0.z; t.id = __float_as_uint(r0.w);
+    t.e1x = r1.x; t.e1y = r1.y; t.e1z = r1.z;
+    t.e2x = r2.x; t.e2y = r2.y; t.e2z = r2.z;
+    t.m12 = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(r2.w) << 32) | __float_as_uint(r1.w)));
+    return t;
+}
+
+// GridAccel::Intersect (Serial/grid.h:167-231) for the 64 rays of a wavefront at once. Every lane must call it.
+//   ANY_HIT: the shadow query. The reference ORs every voxel's result over the whole walk and ignores t,
+//   so leaving at the first passing triangle returns the same value.
+//   SHARED_ORIGIN: all rays start at (ox,oy,oz) of lane 0 (primary rays); the origin-dependent part of the
+//   triangle test is then evaluated once per triangle instead of once per ray.
+//   early (primary rays): leave once the nearest hit so far lies before the next voxel crossing.
+//
+// The walk alternates two phases until every ray is done.
+//   STEP  every live lane advances its own DDA through empty voxels (occupancy bitmap in LDS) until it stands
+//         in an occupied voxel or has left the grid.
+//   TEST  the live lanes are grouped by the voxel they stand in. For each such voxel the wavefront turns round:
+//         the voxel's triangle records are read 64 at a time, ONE PER LANE (consecutive 48-byte records, a
+//         coalesced stream straight from HBM/L2 into registers, next chunk prefetched), and the rays standing in
+//         the voxel are broadcast one after the other through scalar registers and tested against the 64
+//         triangles at once. A record is therefore loaded once per voxel visit of the tile, not once per ray,
+//         and lane utilisation is the voxel's fill of its last 64-chunk, whatever the number of rays sharing it.
+//         The reference tests a voxel's triangles in ascending index and updates (global_t, nearest triangle)
+//         after each one; here the passing lanes of a chunk are applied in ascending lane order, which is the
+//         same order, so the float rounding of global_t between updates is reproduced.
+//
+// Triangle::Intersect (Serial/geometry.h:131-177): the four 3x3 determinants share their 2x2 minors over the
+// y,z rows; evaluating each minor once changes no bit because negating a minor is exact and the t1 - t2 + t3
+// association is kept. With P(u,v) = u.y*v.z - v.y*u.z:
 //   A     = e1.x*P(e2,d) - e2.x*P(e1,d) + d.x*P(e1,e2)
 //   tnum  = e1.x*P(e2,s) - e2.x*P(e1,s) + s.x*P(e1,e2)
 //   bnum  =  s.x*P(e2,d) - e2.x*P(s,d)  - d.x*P(e2,s)
 //   gnum  = e1.x*P(s,d)  -  s.x*P(e1,d) + d.x*P(e1,s)
 // The divisions are only executed when the signs allow beta > 0 and gamma > 0 and the numerators allow
 // beta + gamma < 1 with a 1e-12 relative margin; inside that margin the reference's own expression decides.
-template <bool ANY_HIT>
-__device__ __forceinline__ bool tri_test(float4 r0, float4 r1, float4 r2, float ox, float oy, float oz, double dx, double dy,
-                                         double dz, bool use_eps, float eps, Nearest& st) {
-    const double e1x = r1.x, e1y = r1.y, e1z = r1.z;
-    const double e2x = r2.x, e2y = r2.y, e2z = r2.z;
-    const double sx = r0.x - ox, sy = r0.y - oy, sz = r0.z - oz;       // float subtractions, then widened
-    const double m12 = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(r2.w) << 32) | __float_as_uint(r1.w)));
-    const double p_e2d = e2y * dz - dy * e2z;
-    const double p_e1d = e1y * dz - dy * e1z;
-    const double p_sd = sy * dz - dy * sz;
-    const double A = e1x * p_e2d - e2x * p_e1d + dx * m12;
-    const double p_e2s = e2y * sz - sy * e2z;
-    const double p_e1s = e1y * sz - sy * e1z;
-    const double bnum = sx * p_e2d - e2x * p_sd - dx * p_e2s;
-    const double gnum = e1x * p_sd - sx * p_e1d + dx * p_e1s;
-    const bool pos = (A > 0.0) && (bnum > 0.0) && (gnum > 0.0);
-    const bool neg = (A < 0.0) && (bnum < 0.0) && (gnum < 0.0);
-    if (!(pos || neg)) return false;
-    const double sum = bnum + gnum;
-    if (fabs(sum) > fabs(A) * (1.0 + 1e-12)) return false;
-    const double beta = bnum / A;
-    const double gamma = gnum / A;
-    if (!(beta > 0 && gamma > 0 && beta + gamma < 1)) return false;
-    if (ANY_HIT) return true;
-    const double tnum = e1x * p_e2s - e2x * p_e1s + sx * m12;
-    const double t = tnum / A;
-    if (t < (double)st.t) {
-        if (!use_eps || t > (double)eps) {
-            st.t = (float)t;
-            st.id = (int)__float_as_uint(r0.w);
-        }
-    }
-    return true;
-}
-
-// GridAccel::Intersect, Serial/grid.h:167-231, one ray per lane.
-//   ANY_HIT: the shadow query. The reference ORs every voxel's result over the whole walk and ignores t,
-//   so leaving at the first passing triangle returns the same value.
-//   EARLY (primary rays): leave once the nearest hit so far lies before the next voxel crossing.
-struct WalkCount {           // work counters of one ray (only maintained by the counting build of the kernel)
-    uint32_t entered, steps, tests;
-};
-
-template <bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ bool grid_walk(const GridU& g, const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ occupancy,
-                                          const float4* __restrict__ recs, float ox, float oy, float oz, float dx, float dy, float dz,
-                                          float mint, bool use_eps, float eps, bool early, float slack, Nearest& st, WalkCount& wc) {
-    const float o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
-    // bounds.Inside(ray(mint)), Serial/geometry.h:287-289
-    float rayT;
-    const float px = ox + dx * mint, py = oy + dy * mint, pz = oz + dz * mint;
-    const bool inside = px >= g.lo[0] && px <= g.hi[0] && py >= g.lo[1] && py <= g.hi[1] && pz >= g.lo[2] && pz <= g.hi[2];
-    if (inside) {
-        rayT = mint;
-    } else {
-        // boundingBox::Intersect, Serial/geometry.h:291-316
-        float t0 = mint, t1 = INFINITY;
+template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT>
+__device__ __forceinline__ bool wave_walk(const GridU& g, const RtSceneDev& s, const uint32_t* bitmap, int lane, bool active, float ox,
+                                          float oy, float oz, float dx, float dy, float dz, float mint, bool use_eps, float eps,
+                                          bool early, float slack, Nearest& st, WalkCount& wc) {
+    Dda w;
+    bool alive = false;
+    if (active) {
+        float rayT;
+        alive = grid_entry(g, ox, oy, oz, dx, dy, dz, mint, rayT);
+        if (alive) {
+            if (COUNT) { wc.entered = 1; wc.steps = 1; }
+            const float gi[3] = {ox + dx * rayT, oy + dy * rayT, oz + dz * rayT};
+            const float d[3] = {dx, dy, dz};
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            float inv = 1.f / d[i];
-            float tn = (g.lo[i] - o[i]) * inv;
-            float tf = (g.hi[i] - o[i]) * inv;
-            if (tn > tf) { float x = tn; tn = tf; tf = x; }
-            t0 = tn > t0 ? tn : t0;
-            t1 = tf < t1 ? tf : t1;
-            if (t0 > t1) return false;
-        }
-        rayT = t0;
-    }
-    if (COUNT) wc.entered = 1;
-    const float gi[3] = {ox + dx * rayT, oy + dy * rayT, oz + dz * rayT};
-    float next[3], delta[3];
-    int pos[3], step[3], out[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        pos[a] = pos_to_voxel(gi[a], g.lo[a], g.inv_width[a], g.n[a]);
-        if (d[a] >= 0) {
-            next[a] = rayT + ((g.lo[a] + (float)(pos[a] + 1) * g.width[a]) - gi[a]) / d[a];
-            delta[a] = g.width[a] / d[a];
-            step[a] = 1; out[a] = g.n[a];
-        } else {
-            next[a] = rayT + ((g.lo[a] + (float)pos[a] * g.width[a]) - gi[a]) / d[a];
-            delta[a] = -g.width[a] / d[a];
-            step[a] = -1; out[a] = -1;
-        }
-    }
-    const double ddx = dx, ddy = dy, ddz = dz;
-    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
-    bool hit = false;
-    for (;;) {
-        const int c = pos[2] * nxy + pos[1] * nx + pos[0];
-        if (COUNT) ++wc.steps;
-        if ((occupancy[c >> 5] >> (c & 31)) & 1u) {
-            const uint32_t beg = cell_start[c], end = cell_start[c + 1];
-            for (uint32_t k = beg; k < end; ++k) {
-                const float4* r = recs + 3ull * k;
-                if (COUNT) ++wc.tests;
-                if (tri_test<ANY_HIT>(r[0], r[1], r[2], ox, oy, oz, ddx, ddy, ddz, use_eps, eps, st)) {
-                    if (ANY_HIT) return true;
-                    hit = true;
+            for (int a = 0; a < 3; ++a) {
+                w.pos[a] = pos_to_voxel(gi[a], g.lo[a], g.inv_width[a], g.n[a]);
+                if (d[a] >= 0) {
+                    w.next[a] = rayT + ((g.lo[a] + (float)(w.pos[a] + 1) * g.width[a]) - gi[a]) / d[a];
+                    w.delta[a] = g.width[a] / d[a];
+                } else {
+                    w.next[a] = rayT + ((g.lo[a] + (float)w.pos[a] * g.width[a]) - gi[a]) / d[a];
+                    w.delta[a] = -g.width[a] / d[a];
                 }
             }
+            w.cell = w.pos[2] * g.n[0] * g.n[1] + w.pos[1] * g.n[0] + w.pos[0];
         }
-        // stepAxis through the 3-bit compare table {2,1,2,1,2,2,0,0}, Serial/grid.h:217-221
-        const int bits = ((next[0] < next[1]) << 2) + ((next[0] < next[2]) << 1) + (next[1] < next[2]);
-        const int ax = (0x0A66 >> (2 * bits)) & 3;     // 2-bit entries of the table, entry 0 in the low bits
-        const float nx_t = ax == 0 ? next[0] : (ax == 1 ? next[1] : next[2]);
-        if (early && hit) {
-            const float lim = st.t + fabsf(st.t) * slack;
-            if (lim < nx_t) break;
+    }
+    bool hit = false;
+    bool first = true;
+    const double ddx = dx, ddy = dy, ddz = dz;
+    for (;;) {
+        // ---- STEP: on to the next occupied voxel
+        const long long t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        if (alive && !first) {
+            alive = dda_advance(w, g, dx, dy, dz, early && hit, st.t, slack);
+            if (COUNT && alive) ++wc.steps;
         }
-        if (ax == 0) { pos[0] += step[0]; if (pos[0] == out[0]) break; next[0] += delta[0]; }
-        else if (ax == 1) { pos[1] += step[1]; if (pos[1] == out[1]) break; next[1] += delta[1]; }
-        else { pos[2] += step[2]; if (pos[2] == out[2]) break; next[2] += delta[2]; }
+        first = false;
+        while (alive && !((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u)) {
+            alive = dda_advance(w, g, dx, dy, dz, early && hit, st.t, slack);
+            if (COUNT && alive) ++wc.steps;
+        }
+        unsigned long long un = __ballot(alive);
+        if (!un) break;
+        uint32_t cbeg = 0, cend = 0;
+        if (alive) { cbeg = s.cell_start[w.cell]; cend = s.cell_start[w.cell + 1]; }
+        const long long t1 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        if (COUNT) { wc.rounds += 1; wc.cyc_step += (uint32_t)(t1 - t0); if (alive) wc.tests += cend - cbeg; }
+        // ---- TEST: one voxel after the other
+        while (un) {
+            const int leader = __ffsll((long long)un) - 1;
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)cbeg, leader);
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)cend, leader);
+            unsigned long long members = __ballot(alive && cbeg == b);
+            un &= ~members;
+            if (COUNT) wc.slots += 1;
+            // first chunk
+            float4 n0, n1, n2;
+            {
+                const uint32_t k = b + lane;
+                const float4* r = s.recs + 3ull * (k < e ? k : b);
+                n0 = r[0]; n1 = r[1]; n2 = r[2];
+            }
+            for (uint32_t base = b; base < e; base += 64) {
+                const bool have = base + lane < e;
+                const TriRec t = unpack_rec(n0, n1, n2);
+                if (base + 64 < e) {       // prefetch the next chunk while this one is tested
+                    const uint32_t k = base + 64 + lane;
+                    const float4* r = s.recs + 3ull * (k < e ? k : b);
+                    n0 = r[0]; n1 = r[1]; n2 = r[2];
+                }
+                // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
+                double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
+                if (SHARED_ORIGIN) {
+                    sx = t.v0x - ox; sy = t.v0y - oy; sz = t.v0z - oz;        // float subtractions, then widened
+                    p_e2s = t.e2y * sz - sy * t.e2z;
+                    p_e1s = t.e1y * sz - sy * t.e1z;
+                }
+                unsigned long long lm = members;
+                while (lm) {
+                    const int i = __ffsll((long long)lm) - 1;
+                    lm &= lm - 1;
+                    const double rdx = bcast_f64(ddx, i), rdy = bcast_f64(ddy, i), rdz = bcast_f64(ddz, i);
+                    if (!SHARED_ORIGIN) {
+                        const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
+                        sx = t.v0x - rox; sy = t.v0y - roy; sz = t.v0z - roz;
+                        p_e2s = t.e2y * sz - sy * t.e2z;
+                        p_e1s = t.e1y * sz - sy * t.e1z;
+                    }
+                    const double p_e2d = t.e2y * rdz - rdy * t.e2z;
+                    const double p_e1d = t.e1y * rdz - rdy * t.e1z;
+                    const double p_sd = sy * rdz - rdy * sz;
+                    const double A = t.e1x * p_e2d - t.e2x * p_e1d + rdx * t.m12;
+                    const double bnum = sx * p_e2d - t.e2x * p_sd - rdx * p_e2s;
+                    const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
+                    const bool pos = (A > 0.0) && (bnum > 0.0) && (gnum > 0.0);
+                    const bool neg = (A < 0.0) && (bnum < 0.0) && (gnum < 0.0);
+                    bool pass = false;
+                    double tt = 0.0;
+                    if (have && (pos || neg) && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12))) {
+                        const double beta = bnum / A;
+                        const double gamma = gnum / A;
+                        if (beta > 0 && gamma > 0 && beta + gamma < 1) {
+                            pass = true;
+                            if (!ANY_HIT) {
+                                const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
+                                tt = tnum / A;
+                            }
+                        }
+                    }
+                    unsigned long long pm = __ballot(pass);
+                    if (pm) {
+                        if (ANY_HIT) {
+                            members &= ~(1ull << i);
+                            if (lane == i) {
+                                hit = true; alive = false;
+                                if (COUNT) wc.tests -= e - (base + (uint32_t)__ffsll((long long)pm));   // tests the reference order skips
+                            }
+                        } else {
+                            if (lane == i) hit = true;
+                            // apply the passing triangles in ascending lane order = ascending triangle order
+                            while (pm) {
+                                const int pl = __ffsll((long long)pm) - 1;
+                                pm &= pm - 1;
+                                const double t_p = bcast_f64(tt, pl);
+                                const int id_p = __builtin_amdgcn_readlane((int)t.id, pl);
+                                if (lane == i) {
+                                    if (t_p < (double)st.t) {
+                                        if (!use_eps || t_p > (double)eps) { st.t = (float)t_p; st.id = id_p; }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (ANY_HIT && !members) break;
+            }
+        }
+        if (COUNT) wc.cyc_test += (uint32_t)((long long)__builtin_amdgcn_s_memtime() - t1);
     }
     return hit;
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK_THREADS) k_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o) {
-    // pixel of this lane: 4 wavefronts per block, one 8x8 tile each, tiles laid out left to right
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int tiles_x = (f.width + RT_TILE - 1) / RT_TILE;
-    const int tile = blockIdx.x * 4 + wv;
-    const int tx = tile % tiles_x, ty_local = tile / tiles_x;                 // ty_local = band of this part
-    const int x = tx * RT_TILE + (lane & 7);
-    const int y_local = ty_local * RT_TILE + (lane >> 3);
-    const int y = (ty_local * f.part_count + f.part_index) * RT_TILE + (lane >> 3);   // row in the full frame
-    if (ty_local * RT_TILE >= f.out_rows) return;
-    const bool live = (x < f.width) && (y < f.height);
+__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o,
+                                                                    uint32_t* work, const uint32_t* __restrict__ tile_list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
 
-    GridU g;
+    const uint32_t n_listed = work[0];
+    if (n_listed == 0) return;
+    const GridU g = load_grid(s.grid);
     {
-        const RtGrid* gp = s.grid;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            g.lo[a] = gp->lo[a]; g.hi[a] = gp->hi[a]; g.width[a] = gp->width[a]; g.inv_width[a] = gp->inv_width[a];
-            g.n[a] = gp->n[a];
-        }
+        // occupancy bitmap of the whole grid into LDS, once per block
+        const int words = (s.grid->n_cells + 31) >> 5;
+        for (int i = threadIdx.x; i < words; i += blockDim.x) bitmap[i] = s.occupancy[i];
+        __syncthreads();
     }
 
-    float cr = 0.f, cg = 0.f, cb = 0.f;
-    int id = -1;
-    bool shadowed = false;
-    WalkCount wp = {0, 0, 0}, ws = {0, 0, 0};
-    if (live && s.n_tris > 0) {
-        // ray generation, Serial/raytracer.cpp:153-161; xw and yw are evaluated in double
-        float dx = 0.f + (-cam.w[0]) * cam.focal_distance;
-        float dy = 0.f + (-cam.w[1]) * cam.focal_distance;
-        float dz = 0.f + (-cam.w[2]) * cam.focal_distance;
-        const float xw = (float)((double)cam.aspect * ((double)x - (double)f.width / 2.0 + 0.5) / (double)f.width);
-        const float yw = (float)(((double)y - (double)f.height / 2.0 + 0.5) / (double)f.height);
-        dx = dx + cam.u[0] * xw; dy = dy + cam.u[1] * xw; dz = dz + cam.u[2] * xw;
-        dx = dx + cam.v[0] * yw; dy = dy + cam.v[1] * yw; dz = dz + cam.v[2] * yw;
-        normalize3(dx, dy, dz);
+    // Work unit of a wavefront: a whole 8x8 tile (64 rays), or half (8x4) or a quarter (4x4) of one when the
+    // frame lists few tiles per wavefront, so that the longest-running tile does not set the frame time.
+    const uint32_t n_waves = gridDim.x * RT_WAVES_PER_BLOCK;
+    const int ushift = (n_listed >= 24u * n_waves) ? 0 : ((n_listed >= 12u * n_waves) ? 1 : 2);
+    const uint32_t n_units = n_listed << ushift;
+    for (;;) {
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(&work[1], 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= n_units) break;
+        const int tile = (int)tile_list[slot >> ushift];
+        const int sub = (int)(slot & ((1u << ushift) - 1u));
+        // lane -> pixel of the tile: ushift 0: all 64 lanes, row-major 8x8; 1: lanes 0..31 cover rows 4*sub..4*sub+3;
+        // 2: lanes 0..15 cover the 4x4 quadrant `sub`
+        int tl = lane;
+        bool in_unit = true;
+        if (ushift == 1) { in_unit = lane < 32; tl = sub * 32 + (lane & 31); }
+        else if (ushift == 2) { in_unit = lane < 16; tl = ((sub >> 1) * 4 + ((lane >> 2) & 3)) * 8 + (sub & 1) * 4 + (lane & 3); }
+        int x, y_local, y;
+        tile_pixel(f, tile, tl, x, y_local, y);
+        const bool live = in_unit && (x < f.width) && (y < f.height);
+
+        float dx = 0.f, dy = 0.f, dz = 1.f;
+        if (live) primary_ray(cam, f, x, y, dx, dy, dz);
 
         // fast_trace, Serial/raytracer.cpp:71-118
         Nearest st = {INFINITY, -1};
-        const bool hit = grid_walk<false, COUNT>(g, s.cell_start, s.occupancy, s.recs, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz,
-                                                 0.f, false, sh.eps, f.walk_full == 0, f.early_slack, st, wp);
+        WalkCount wp = {0, 0, 0, 0, 0, 0, 0, 0}, ws = {0, 0, 0, 0, 0, 0, 0, 0};
+        const long long t_start = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const bool hit = wave_walk<false, true, COUNT>(g, s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
+                                                       sh.eps, f.walk_full == 0, f.early_slack, st, wp);
+        float cr = 0.f, cg = 0.f, cb = 0.f;
+        float colr = 0.f, colg = 0.f, colb = 0.f;
+        float poix = 0.f, poiy = 0.f, poiz = 0.f, sx = 0.f, sy = 0.f, sz = 1.f;
+        int id = -1;
         if (hit) {
             id = st.id;
             const float4 p0 = s.v0[id], p1 = s.v1[id], p2 = s.v2[id];
             const uint32_t mesh = __float_as_uint(p0.w);
-            const float colr = s.mesh_color[3 * mesh], colg = s.mesh_color[3 * mesh + 1], colb = s.mesh_color[3 * mesh + 2];
-            const float poix = cam.pos[0] + dx * st.t, poiy = cam.pos[1] + dy * st.t, poiz = cam.pos[2] + dz * st.t;
+            colr = s.mesh_color[3 * mesh]; colg = s.mesh_color[3 * mesh + 1]; colb = s.mesh_color[3 * mesh + 2];
+            poix = cam.pos[0] + dx * st.t; poiy = cam.pos[1] + dy * st.t; poiz = cam.pos[2] + dz * st.t;
             float vx = -dx, vy = -dy, vz = -dz;
             normalize3(vx, vy, vz);
             float lx = sh.light[0] - poix, ly = sh.light[1] - poiy, lz = sh.light[2] - poiz;
@@ -519,52 +746,64 @@ __global__ void __launch_bounds__(RT_BLOCK_THREADS) k_render(RtSceneDev s, RtCam
             cg = (colg * fs) * sh.light_intensity + (colg * fd) * sh.light_intensity;
             cb = (colb * fs) * sh.light_intensity + (colb * fd) * sh.light_intensity;
             // shadow ray, Serial/raytracer.cpp:106-113: away from the light, starting at eps
-            float sx = -(sh.light[0] - poix), sy = -(sh.light[1] - poiy), sz = -(sh.light[2] - poiz);
+            sx = -(sh.light[0] - poix); sy = -(sh.light[1] - poiy); sz = -(sh.light[2] - poiz);
             normalize3(sx, sy, sz);
-            shadowed = grid_walk<true, COUNT>(g, s.cell_start, s.occupancy, s.recs, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
-                                              true, 0.f, st, ws);
+        }
+        const bool shadowed = wave_walk<true, false, COUNT>(g, s, bitmap, lane, hit, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
+                                                            true, 0.f, st, ws);
+        if (hit) {
             if (shadowed) { cr = cr * sh.shadow_scale; cg = cg * sh.shadow_scale; cb = cb * sh.shadow_scale; }
             cr = cr + colr * sh.ka; cg = cg + colg * sh.ka; cb = cb + colb * sh.ka;
         }
-    }
-    if (o.counters) {
-        const unsigned long long hm = __ballot(id >= 0), sm = __ballot(shadowed);
-        if (lane == 0) {
-            if (hm) atomicAdd(&o.counters[0], (unsigned long long)__popcll(hm));
-            if (sm) atomicAdd(&o.counters[1], (unsigned long long)__popcll(sm));
-        }
-        if (COUNT) {
-            uint32_t v[6] = {wp.entered, wp.steps, wp.tests, ws.entered, ws.steps, ws.tests};
+        if (o.counters) {
+            const unsigned long long hm = __ballot(hit), sm = __ballot(shadowed);
+            if (lane == 0) {
+                if (hm) atomicAdd(&o.counters[0], (unsigned long long)__popcll(hm));
+                if (sm) atomicAdd(&o.counters[1], (unsigned long long)__popcll(sm));
+            }
+            if (COUNT) {
+                uint32_t v[6] = {wp.entered, wp.steps, wp.tests, ws.entered, ws.steps, ws.tests};
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                unsigned long long t = v[k];
+                for (int k = 0; k < 6; ++k) {
+                    unsigned long long t = v[k];
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-                if (lane == 0 && t) atomicAdd(&o.counters[2 + k], t);
+                    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+                    if (lane == 0 && t) atomicAdd(&o.counters[2 + k], t);
+                }
+                if (lane == 0) {
+                    const unsigned long long cyc = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_start);
+                    atomicAdd(&o.counters[8], (unsigned long long)(wp.rounds + ws.rounds));
+                    atomicAdd(&o.counters[9], (unsigned long long)(wp.slots + ws.slots));
+                    atomicAdd(&o.counters[10], (unsigned long long)(wp.cyc_step + ws.cyc_step));
+                    atomicAdd(&o.counters[15], (unsigned long long)(wp.cyc_test + ws.cyc_test));
+                    atomicMax(&o.counters[11], cyc);
+                    atomicAdd(&o.counters[12], cyc);
+                    atomicAdd(&o.counters[13], 1ull);
+                    atomicMax(&o.counters[14], (unsigned long long)(wp.rounds + ws.rounds));
+                }
             }
         }
-    }
-    if (x < f.width && y_local < f.out_rows) {
-        const size_t pix = (size_t)y_local * f.width + x;
-        if (o.rgb_f32) { o.rgb_f32[3 * pix] = cr; o.rgb_f32[3 * pix + 1] = cg; o.rgb_f32[3 * pix + 2] = cb; }
-        if (o.rgb_u8) {
-            // PPM quantisation, Serial/raytracer.cpp:181-183: (unsigned char)(min(1, c/255)*255); a NaN gives 255
-            o.rgb_u8[3 * pix] = (uint8_t)(min_std(1.f, cr / 255) * 255);
-            o.rgb_u8[3 * pix + 1] = (uint8_t)(min_std(1.f, cg / 255) * 255);
-            o.rgb_u8[3 * pix + 2] = (uint8_t)(min_std(1.f, cb / 255) * 255);
-        }
-        if (o.hit_id) o.hit_id[pix] = id;
+        if (in_unit) write_pixel(f, o, x, y_local, cr, cg, cb, id);
     }
 }
 
-hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, hipStream_t st) {
+hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st) {
     const int tiles_x = (f.width + RT_TILE - 1) / RT_TILE;
     const int tiles_y = (f.out_rows + RT_TILE - 1) / RT_TILE;
     const int tiles = tiles_x * tiles_y;
     if (tiles <= 0) return hipSuccess;
-    if (f.count_work) k_render<true><<<(tiles + 3) / 4, RT_BLOCK_THREADS, 0, st>>>(s, cam, sh, f, o);
-    else k_render<false><<<(tiles + 3) / 4, RT_BLOCK_THREADS, 0, st>>>(s, cam, sh, f, o);
+    k_classify<<<(tiles + 3) / 4, 256, 0, st>>>(s, cam, f, o, wk.work, wk.tile_list, tiles);
+    const size_t lds = rt_trace_lds_bytes(wk.bitmap_words);
+    int blocks = wk.n_cu * wk.blocks_per_cu;
+    const int max_useful = (tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK;
+    if (blocks > max_useful) blocks = max_useful;
+    if (f.count_work) k_trace<true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(s, cam, sh, f, o, wk.work, wk.tile_list);
+    else k_trace<false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(s, cam, sh, f, o, wk.work, wk.tile_list);
     return hipGetLastError();
+}
+
+size_t rt_trace_lds_bytes(int bitmap_words) {
+    return (size_t)bitmap_words * 4;
 }
 
 // ------------------------------------------------------------------------------------------------

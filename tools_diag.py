@@ -1,0 +1,17 @@
+"""Scheduling diagnostics of the trace kernel for one workload (GPU)."""
+import importlib, sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench
+rt = importlib.import_module("ray-tracer_amd")
+for w in sys.argv[1:]:
+    scene, pkw, W, H, label = bench.build_workload(rt, w)
+    p = rt.default_params(W, H, **pkw)
+    scene.render(p, want_rgb=False, want_ids=False, want_u8=True)
+    scene.set_counting(True)
+    scene.render(p, want_rgb=False, want_ids=False, want_u8=True)
+    st = scene.last_stats()
+    t = max(st["tiles_traced"], 1); r = max(st["sched_rounds"], 1)
+    print(w, "ms_render(count)", round(st["ms_render"], 3), "tiles", st["tiles_traced"], "rounds/tile", round(st["sched_rounds"] / t, 1),
+          "max rounds", st["tile_rounds_max"], "streams/round", round(st["sched_streams"] / r, 2), "cyc step/tile", int(st["sched_lanes"] / t), "cyc test/tile", int(st["cycles_test"] / t),
+          "tile cycles avg", int(st["tile_cycles_sum"] / t), "max", st["tile_cycles_max"],
+          "tests", st["tests_primary"] + st["tests_shadow"], "steps", st["steps_primary"] + st["steps_shadow"])
