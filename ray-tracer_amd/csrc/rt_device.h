@@ -82,7 +82,7 @@ struct RtBuildDev {
     uint32_t* block_sums;         // RT_MAX_SCAN_BLOCKS
     uint32_t* occupancy;          // RT_MAX_CELLS / 32
     uint32_t* ref_tri;            // ref_cap, unsorted
-    uint32_t* ref_cell;           // ref_cap
+    uint32_t* ref_cell;           // ref_cap: voxel of each unsorted reference
     float4* recs;                 // 3 * ref_cap
     uint32_t ref_cap;
     unsigned long long* counters;

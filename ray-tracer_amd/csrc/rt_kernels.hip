@@ -80,7 +80,8 @@ __global__ void k_build_init(RtBuildDev b) {
 }
 
 // Scene bounds (Serial/grid.h:82-86): min/max over all vertices. Exact and order-independent.
-__global__ void k_bounds(RtBuildDev b) {
+__global__ void __launch_bounds__(256) k_bounds(RtBuildDev b) {
+    __shared__ float red[4][6];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n_tris; i += stride) {
@@ -97,12 +98,18 @@ __global__ void k_bounds(RtBuildDev b) {
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&b.bounds_enc[a], enc_f32(lo[a]));
-            atomicMax(&b.bounds_enc[3 + a], enc_f32(hi[a]));
-        }
+        for (int a = 0; a < 3; ++a) { red[wv][a] = lo[a]; red[wv][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float v = red[0][a];
+        for (int k = 1; k < 4; ++k) v = (a < 3) ? fminf(v, red[k][a]) : fmaxf(v, red[k][a]);
+        if (a < 3) atomicMin(&b.bounds_enc[a], enc_f32(v));
+        else atomicMax(&b.bounds_enc[a], enc_f32(v));
     }
 }
 
@@ -144,19 +151,33 @@ __device__ __forceinline__ void tri_voxel_range(const RtBuildDev& b, const RtGri
     }
 }
 
-// COUNT: one thread per triangle, one atomic per overlapped voxel.
-__global__ void k_count(RtBuildDev b) {
+// COUNT: one thread per triangle. Most triangles lie in a single voxel and neighbouring triangle indices
+// tend to share it, so the lanes of a wavefront that hit the same voxel are counted with one atomic;
+// triangles that span several voxels add one atomic per voxel.
+__global__ void __launch_bounds__(256) k_count(RtBuildDev b) {
     __shared__ RtGrid g;
     if (threadIdx.x == 0) g = *b.grid;
     __syncthreads();
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n_tris) return;
-    int vmin[3], vmax[3];
-    tri_voxel_range(b, g, i, vmin, vmax);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < b.n_tris;
+    int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
+    if (valid) tri_voxel_range(b, g, i, vmin, vmax);
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
-    for (int z = vmin[2]; z <= vmax[2]; ++z)
-        for (int y = vmin[1]; y <= vmax[1]; ++y)
-            for (int x = vmin[0]; x <= vmax[0]; ++x) atomicAdd(&b.cell_count[z * nxy + y * nx + x], 1u);
+    const bool single = valid && vmin[0] == vmax[0] && vmin[1] == vmax[1] && vmin[2] == vmax[2];
+    const int c = vmin[2] * nxy + vmin[1] * nx + vmin[0];
+    unsigned long long rem = __ballot(single);
+    while (rem) {
+        const int l = __ffsll((long long)rem) - 1;
+        const int c0 = __builtin_amdgcn_readlane(c, l);
+        const unsigned long long m = __ballot(single && c == c0);
+        if (lane == l) atomicAdd(&b.cell_count[c0], (uint32_t)__popcll(m));
+        rem &= ~m;
+    }
+    if (valid && !single)
+        for (int z = vmin[2]; z <= vmax[2]; ++z)
+            for (int y = vmin[1]; y <= vmax[1]; ++y)
+                for (int x = vmin[0]; x <= vmax[0]; ++x) atomicAdd(&b.cell_count[z * nxy + y * nx + x], 1u);
 }
 
 // SCAN part 1: per-chunk totals. A chunk is RT_SCAN_CHUNK consecutive cells, one 256-thread block each.
@@ -226,52 +247,109 @@ __global__ void k_scan_apply(RtBuildDev b) {
     }
 }
 
-// SCATTER: claims a slot in the voxel's segment by counting cell_count back down to zero.
-__global__ void k_scatter(RtBuildDev b) {
+// SCATTER: claims slots in the voxel's segment by counting cell_count back down to zero, with the same
+// per-wavefront aggregation as COUNT. The order inside a voxel is whatever the atomics produce; k_order_emit
+// restores ascending triangle index afterwards.
+__global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
     __shared__ RtGrid g;
     if (threadIdx.x == 0) g = *b.grid;
     __syncthreads();
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n_tris) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     if (g.n_refs > b.ref_cap) { if (i == 0) b.grid->overflow = 1; return; }
-    int vmin[3], vmax[3];
-    tri_voxel_range(b, g, i, vmin, vmax);
+    const bool valid = i < b.n_tris;
+    int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
+    if (valid) tri_voxel_range(b, g, i, vmin, vmax);
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
-    for (int z = vmin[2]; z <= vmax[2]; ++z)
-        for (int y = vmin[1]; y <= vmax[1]; ++y)
-            for (int x = vmin[0]; x <= vmax[0]; ++x) {
-                uint32_t c = z * nxy + y * nx + x;
-                uint32_t slot = atomicSub(&b.cell_count[c], 1u) - 1u;
-                uint32_t pos = b.cell_start[c] + slot;
-                b.ref_tri[pos] = i;
-                b.ref_cell[pos] = c;
-            }
+    const bool single = valid && vmin[0] == vmax[0] && vmin[1] == vmax[1] && vmin[2] == vmax[2];
+    const int c = vmin[2] * nxy + vmin[1] * nx + vmin[0];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned long long rem = __ballot(single);
+    while (rem) {
+        const int l = __ffsll((long long)rem) - 1;
+        const int c0 = __builtin_amdgcn_readlane(c, l);
+        const bool mine = single && c == c0;
+        const unsigned long long m = __ballot(mine);
+        uint32_t old = 0;
+        if (lane == l) old = atomicSub(&b.cell_count[c0], (uint32_t)__popcll(m));
+        old = (uint32_t)__builtin_amdgcn_readlane((int)old, l);
+        if (mine) {
+            const uint32_t pos = b.cell_start[c0] + old - 1u - (uint32_t)__popcll(m & lt_mask);
+            b.ref_tri[pos] = i;
+            b.ref_cell[pos] = (uint32_t)c0;
+        }
+        rem &= ~m;
+    }
+    if (valid && !single)
+        for (int z = vmin[2]; z <= vmax[2]; ++z)
+            for (int y = vmin[1]; y <= vmax[1]; ++y)
+                for (int x = vmin[0]; x <= vmax[0]; ++x) {
+                    const uint32_t cc = z * nxy + y * nx + x;
+                    const uint32_t slot = atomicSub(&b.cell_count[cc], 1u) - 1u;
+                    b.ref_tri[b.cell_start[cc] + slot] = i;
+                    b.ref_cell[b.cell_start[cc] + slot] = cc;
+                }
 }
 
-// ORDER + EMIT: the reference appends triangles to a voxel in ascending index (Serial/grid.h:118-150)
-// and the first-tested triangle wins ties, so every voxel's list is put back into ascending order: each
-// reference counts the smaller indices in its voxel (indices are distinct) and writes its 48-byte record
-// at that rank. Record = {v0.xyz, id}, {v0-v1, lo32(m)}, {v0-v2, hi32(m)} with m the double
+// Record of one (voxel, triangle) reference: {v0.xyz, id}, {v0-v1, lo32(m)}, {v0-v2, hi32(m)} with m the double
 // (e1.y*e2.z - e2.y*e1.z), the one 2x2 minor of Triangle::Intersect that does not depend on the ray.
-__global__ void k_order_emit(RtBuildDev b) {
+__device__ __forceinline__ void emit_record(const RtBuildDev& b, uint32_t tri, uint32_t pos) {
+    const float4 p = b.v0[tri], q = b.v1[tri], s = b.v2[tri];
+    const float e1x = p.x - q.x, e1y = p.y - q.y, e1z = p.z - q.z;
+    const float e2x = p.x - s.x, e2y = p.y - s.y, e2z = p.z - s.z;
+    const double m = (double)e1y * (double)e2z - (double)e2y * (double)e1z;
+    const unsigned long long mb = (unsigned long long)__double_as_longlong(m);
+    float4* o = b.recs + 3ull * pos;
+    o[0] = make_float4(p.x, p.y, p.z, __uint_as_float(tri));
+    o[1] = make_float4(e1x, e1y, e1z, __uint_as_float((uint32_t)mb));
+    o[2] = make_float4(e2x, e2y, e2z, __uint_as_float((uint32_t)(mb >> 32)));
+}
+
+#define RT_ORDER_LDS_IDS 2048          // triangle indices of one voxel a wavefront holds in LDS at a time
+
+// ORDER + EMIT: the reference appends triangles to a voxel in ascending index (Serial/grid.h:118-150) and the
+// first-tested triangle wins ties, so every voxel's list is put back into ascending order: each reference
+// counts the smaller indices in its voxel (indices are distinct) and writes its 48-byte record at that rank.
+// A wavefront takes 64 consecutive references. For every voxel these belong to, the voxel's index list is
+// streamed through LDS in tiles and the lanes of that voxel count against it; a crowded voxel is therefore
+// shared out over as many wavefronts as it has 64-reference rows.
+__global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
+    __shared__ __attribute__((aligned(16))) uint32_t ids_all[4][RT_ORDER_LDS_IDS];
     const uint32_t n_refs = b.grid->n_refs;
     if (n_refs > b.ref_cap) return;
-    uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_refs; r += stride) {
-        uint32_t c = b.ref_cell[r];
-        uint32_t beg = b.cell_start[c], end = b.cell_start[c + 1];
-        uint32_t me = b.ref_tri[r];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t* ids = ids_all[wv];
+    const uint32_t n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + wv;
+    const uint32_t n_rows = (n_refs + 63u) / 64u;
+    for (uint32_t row = wave; row < n_rows; row += n_waves) {
+        const uint32_t p = row * 64u + lane;
+        const bool valid = p < n_refs;
+        uint32_t c = 0xffffffffu, me = 0, beg = 0, end = 0;
+        if (valid) { c = b.ref_cell[p]; me = b.ref_tri[p]; beg = b.cell_start[c]; end = b.cell_start[c + 1]; }
         uint32_t rank = 0;
-        for (uint32_t k = beg; k < end; ++k) rank += (b.ref_tri[k] < me) ? 1u : 0u;
-        float4 p = b.v0[me], q = b.v1[me], s = b.v2[me];
-        float e1x = p.x - q.x, e1y = p.y - q.y, e1z = p.z - q.z;
-        float e2x = p.x - s.x, e2y = p.y - s.y, e2z = p.z - s.z;
-        double m = (double)e1y * (double)e2z - (double)e2y * (double)e1z;
-        unsigned long long mb = (unsigned long long)__double_as_longlong(m);
-        float4* o = b.recs + 3ull * (beg + rank);
-        o[0] = make_float4(p.x, p.y, p.z, __uint_as_float(me));
-        o[1] = make_float4(e1x, e1y, e1z, __uint_as_float((uint32_t)mb));
-        o[2] = make_float4(e2x, e2y, e2z, __uint_as_float((uint32_t)(mb >> 32)));
+        unsigned long long rem = __ballot(valid);
+        while (rem) {
+            const int l = __ffsll((long long)rem) - 1;
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, l);
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)beg, l);
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)end, l);
+            const bool mem = valid && c == c0;
+            rem &= ~__ballot(mem);
+            for (uint32_t tile = b0; tile < e0; tile += RT_ORDER_LDS_IDS) {
+                const uint32_t nt = (e0 - tile) < RT_ORDER_LDS_IDS ? (e0 - tile) : RT_ORDER_LDS_IDS;
+                const uint32_t nt4 = (nt + 3u) & ~3u;
+                for (uint32_t k = lane; k < nt4; k += 64) ids[k] = (k < nt) ? b.ref_tri[tile + k] : 0xffffffffu;
+                __builtin_amdgcn_wave_barrier();
+                if (mem) {
+                    for (uint32_t j = 0; j < nt4; j += 4) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(ids + j);
+                        rank += (v.x < me) + (v.y < me) + (v.z < me) + (v.w < me);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (valid) emit_record(b, me, beg + rank);
     }
 }
 
@@ -279,7 +357,7 @@ hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st) {
     k_build_init<<<256, 256, 0, st>>>(b);
     if (b.n_tris) {
         uint32_t nb = (b.n_tris + 255) / 256;
-        k_bounds<<<nb < 1024 ? nb : 1024, 256, 0, st>>>(b);
+        k_bounds<<<nb < 512 ? nb : 512, 256, 0, st>>>(b);
     }
     k_grid_setup<<<1, 64, 0, st>>>(b);
     if (b.n_tris) k_count<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
@@ -291,7 +369,7 @@ hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st) {
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st) {
     if (b.n_tris == 0) return hipSuccess;
     k_scatter<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
-    k_order_emit<<<2048, 256, 0, st>>>(b);
+    k_order_emit<<<1024, 256, 0, st>>>(b);
     return hipGetLastError();
 }
 
