@@ -40,6 +40,7 @@ struct RtFrame {
     int32_t walk_full;            // 1 = walk every primary ray to the grid exit
     float early_slack;
     int32_t count_work;           // 1 = the kernel also counts voxel steps and triangle tests
+    int32_t unit_shift;           // -1 = choose per frame; 0/1/2 = whole, half or quarter tiles per wavefront
 };
 
 // Device pointers of one scene.

@@ -438,6 +438,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.walk_full = (p->walk_mode == RT_WALK_FULL);
     f.early_slack = 0.f;
     f.count_work = s->count_work ? 1 : 0;
+    { const char* e = getenv("RT_UNIT_SHIFT"); f.unit_shift = e ? atoi(e) : -1; }
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;

@@ -511,34 +511,63 @@ __global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, Rt
     }
 }
 
-// DDA state of one ray, Serial/grid.h:182-203.
+// DDA state of one ray, Serial/grid.h:182-203. Pos/Step/Out of the reference are kept in an equivalent form:
+// the linear voxel index, its increment per axis and the number of steps left before the ray leaves the grid
+// along each axis (Pos == Out after left+1 steps).
 struct Dda {
     float next[3], delta[3];
-    int pos[3];
+    int left[3];
+    int cstep[3];
     int cell;
 };
 
+__device__ __forceinline__ void dda_setup(Dda& w, const GridU& g, float ox, float oy, float oz, float dx, float dy, float dz, float rayT) {
+    const float gi[3] = {ox + dx * rayT, oy + dy * rayT, oz + dz * rayT};
+    const float d[3] = {dx, dy, dz};
+    const int stride[3] = {1, g.n[0], g.n[0] * g.n[1]};
+    w.cell = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int pos = pos_to_voxel(gi[a], g.lo[a], g.inv_width[a], g.n[a]);
+        if (d[a] >= 0) {
+            w.next[a] = rayT + ((g.lo[a] + (float)(pos + 1) * g.width[a]) - gi[a]) / d[a];
+            w.delta[a] = g.width[a] / d[a];
+            w.left[a] = g.n[a] - 1 - pos;
+            w.cstep[a] = stride[a];
+        } else {
+            w.next[a] = rayT + ((g.lo[a] + (float)pos * g.width[a]) - gi[a]) / d[a];
+            w.delta[a] = -g.width[a] / d[a];
+            w.left[a] = pos;
+            w.cstep[a] = -stride[a];
+        }
+        w.cell += pos * stride[a];
+    }
+}
+
 // One step of the walk loop, Serial/grid.h:216-227, plus the early-exit rule. Returns false when the ray is done.
-__device__ __forceinline__ bool dda_advance(Dda& w, const GridU& g, float dx, float dy, float dz, bool early_hit, float best_t, float slack) {
-    // stepAxis through the 3-bit compare table {2,1,2,1,2,2,0,0}
-    const int bits = ((w.next[0] < w.next[1]) << 2) + ((w.next[0] < w.next[2]) << 1) + (w.next[1] < w.next[2]);
-    const int ax = (0x0A66 >> (2 * bits)) & 3;
-    const float nx_t = ax == 0 ? w.next[0] : (ax == 1 ? w.next[1] : w.next[2]);
+// stepAxis comes from the 3-bit compare table {2,1,2,1,2,2,0,0}: axis 0 iff next0 < next1 and next0 < next2,
+// axis 1 iff not (next0 < next1) and next1 < next2, else axis 2. Written without branches on the axis.
+__device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t, float slack) {
+    const bool c01 = w.next[0] < w.next[1], c02 = w.next[0] < w.next[2], c12 = w.next[1] < w.next[2];
+    const bool is0 = c01 && c02;
+    const bool is1 = !c01 && c12;
+    const float nx_t = is0 ? w.next[0] : (is1 ? w.next[1] : w.next[2]);
     if (early_hit) {
         const float lim = best_t + fabsf(best_t) * slack;
         if (lim < nx_t) return false;
     }
-    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
-    if (ax == 0) {
-        const int st = dx >= 0 ? 1 : -1, out = dx >= 0 ? g.n[0] : -1;
-        w.pos[0] += st; if (w.pos[0] == out) return false; w.next[0] += w.delta[0]; w.cell += st;
-    } else if (ax == 1) {
-        const int st = dy >= 0 ? 1 : -1, out = dy >= 0 ? g.n[1] : -1;
-        w.pos[1] += st; if (w.pos[1] == out) return false; w.next[1] += w.delta[1]; w.cell += st * nx;
-    } else {
-        const int st = dz >= 0 ? 1 : -1, out = dz >= 0 ? g.n[2] : -1;
-        w.pos[2] += st; if (w.pos[2] == out) return false; w.next[2] += w.delta[2]; w.cell += st * nxy;
-    }
+    const int lf = is0 ? w.left[0] : (is1 ? w.left[1] : w.left[2]);
+    if (lf == 0) return false;                      // Pos[stepAxis] == Out[stepAxis]
+    const float dl = is0 ? w.delta[0] : (is1 ? w.delta[1] : w.delta[2]);
+    const int cs = is0 ? w.cstep[0] : (is1 ? w.cstep[1] : w.cstep[2]);
+    const float nn = nx_t + dl;
+    w.next[0] = is0 ? nn : w.next[0];
+    w.next[1] = is1 ? nn : w.next[1];
+    w.next[2] = (is0 || is1) ? w.next[2] : nn;
+    w.left[0] = is0 ? lf - 1 : w.left[0];
+    w.left[1] = is1 ? lf - 1 : w.left[1];
+    w.left[2] = (is0 || is1) ? w.left[2] : lf - 1;
+    w.cell += cs;
     return true;
 }
 
@@ -610,20 +639,7 @@ __device__ __forceinline__ bool wave_walk(const GridU& g, const RtSceneDev& s, c
         alive = grid_entry(g, ox, oy, oz, dx, dy, dz, mint, rayT);
         if (alive) {
             if (COUNT) { wc.entered = 1; wc.steps = 1; }
-            const float gi[3] = {ox + dx * rayT, oy + dy * rayT, oz + dz * rayT};
-            const float d[3] = {dx, dy, dz};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                w.pos[a] = pos_to_voxel(gi[a], g.lo[a], g.inv_width[a], g.n[a]);
-                if (d[a] >= 0) {
-                    w.next[a] = rayT + ((g.lo[a] + (float)(w.pos[a] + 1) * g.width[a]) - gi[a]) / d[a];
-                    w.delta[a] = g.width[a] / d[a];
-                } else {
-                    w.next[a] = rayT + ((g.lo[a] + (float)w.pos[a] * g.width[a]) - gi[a]) / d[a];
-                    w.delta[a] = -g.width[a] / d[a];
-                }
-            }
-            w.cell = w.pos[2] * g.n[0] * g.n[1] + w.pos[1] * g.n[0] + w.pos[0];
+            dda_setup(w, g, ox, oy, oz, dx, dy, dz, rayT);
         }
     }
     bool hit = false;
@@ -633,12 +649,12 @@ __device__ __forceinline__ bool wave_walk(const GridU& g, const RtSceneDev& s, c
         // ---- STEP: on to the next occupied voxel
         const long long t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (alive && !first) {
-            alive = dda_advance(w, g, dx, dy, dz, early && hit, st.t, slack);
+            alive = dda_advance(w, early && hit, st.t, slack);
             if (COUNT && alive) ++wc.steps;
         }
         first = false;
         while (alive && !((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u)) {
-            alive = dda_advance(w, g, dx, dy, dz, early && hit, st.t, slack);
+            alive = dda_advance(w, early && hit, st.t, slack);
             if (COUNT && alive) ++wc.steps;
         }
         unsigned long long un = __ballot(alive);
@@ -762,7 +778,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s,
     // Work unit of a wavefront: a whole 8x8 tile (64 rays), or half (8x4) or a quarter (4x4) of one when the
     // frame lists few tiles per wavefront, so that the longest-running tile does not set the frame time.
     const uint32_t n_waves = gridDim.x * RT_WAVES_PER_BLOCK;
-    const int ushift = (n_listed >= 24u * n_waves) ? 0 : ((n_listed >= 12u * n_waves) ? 1 : 2);
+    const int ushift = f.unit_shift >= 0 ? f.unit_shift : ((n_listed >= 24u * n_waves) ? 0 : ((n_listed >= 12u * n_waves) ? 1 : 2));
     const uint32_t n_units = n_listed << ushift;
     for (;;) {
         uint32_t slot = 0;
@@ -771,12 +787,14 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s,
         if (slot >= n_units) break;
         const int tile = (int)tile_list[slot >> ushift];
         const int sub = (int)(slot & ((1u << ushift) - 1u));
-        // lane -> pixel of the tile: ushift 0: all 64 lanes, row-major 8x8; 1: lanes 0..31 cover rows 4*sub..4*sub+3;
-        // 2: lanes 0..15 cover the 4x4 quadrant `sub`
-        int tl = lane;
-        bool in_unit = true;
-        if (ushift == 1) { in_unit = lane < 32; tl = sub * 32 + (lane & 31); }
-        else if (ushift == 2) { in_unit = lane < 16; tl = ((sub >> 1) * 4 + ((lane >> 2) & 3)) * 8 + (sub & 1) * 4 + (lane & 3); }
+        // lane -> pixel of the tile: the tile's 64 pixels are numbered along a Z-order curve and unit `sub` owns
+        // 64 >> ushift consecutive ones (a compact 8x8, 8x4, 4x4, 4x2 ... block); the other lanes carry no ray
+        const int per_unit = 64 >> ushift;
+        const bool in_unit = lane < per_unit;
+        const int m = sub * per_unit + (lane & (per_unit - 1));
+        const int mx = (m & 1) | ((m >> 1) & 2) | ((m >> 2) & 4);
+        const int my = ((m >> 1) & 1) | ((m >> 2) & 2) | ((m >> 3) & 4);
+        const int tl = my * 8 + mx;
         int x, y_local, y;
         tile_pixel(f, tile, tl, x, y_local, y);
         const bool live = in_unit && (x < f.width) && (y < f.height);
