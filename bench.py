@@ -74,6 +74,17 @@ def build_workload(rt, name):
     raise SystemExit("unknown workload " + name)
 
 
+def gather_parts(part, world, rank, out=None):
+    """Gathers every rank's stacked bands to rank 0 (RCCL on GPUs; the same call runs over gloo in the CPU tests).
+    Returns [world, rows, W, C] on rank 0 (written into `out` when given) and None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if rank == 0 and out is None:
+        out = torch.empty((world,) + tuple(part.shape), dtype=part.dtype, device=part.device)
+    dist.gather(part, list(out.unbind(0)) if rank == 0 else None, dst=0)
+    return out
+
+
 def cpu_baseline(rt, scene, pkw, W, H, budget_s=12.0):
     """The oracle (C restatement of Serial/, bit-verified against the compiled reference) on ONE host core, in
     the reference's own full-walk mode, on a bounded sample of rows of the same frame."""
@@ -142,15 +153,15 @@ def main():
     rows = rt.part_rows(p)
     dev = torch.device("cuda", local_rank)
     part_u8 = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world, rows, W, 3), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     frame_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+    gathered = torch.empty((world, rows, W, 3), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
     scene.upload()          # triangles resident in HBM before anything is timed
 
     def step():
         scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_u8.data_ptr(), stream=stream)
         if world > 1:
-            dist.gather(part_u8, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            gather_parts(part_u8, world, rank, out=gathered)
             if rank == 0:
                 rt.deinterleave_device(p, gathered.data_ptr(), frame_u8.data_ptr(), 3, stream=stream)
 

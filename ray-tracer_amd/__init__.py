@@ -228,6 +228,35 @@ class Scene:
         _check(lib().rt_scene_set_counting(self.h, int(bool(enable))))
 
 
+def part_row_map(params):
+    """Global frame row of every local row of part params.part_index (-1 for padding rows below the frame):
+    band b of RT_BAND_ROWS rows belongs to part b % part_count, local band j of a part is global band
+    part_index + j * part_count. Host-side statement of the layout rt_render_device() writes."""
+    rows = part_rows(params)
+    out = np.full(rows, -1, np.int64)
+    if params.part_count <= 1:
+        out[:] = np.arange(rows)
+        return out
+    for local in range(rows):
+        band = (local // RT_BAND_ROWS) * params.part_count + params.part_index
+        y = band * RT_BAND_ROWS + local % RT_BAND_ROWS
+        if y < params.height:
+            out[local] = y
+    return out
+
+
+def deinterleave_host(params, stacked):
+    """Host counterpart of rt_deinterleave_device: stacked = [part_count, part_rows, W, ...] -> [H, W, ...]."""
+    stacked = np.asarray(stacked)
+    out = np.zeros((params.height,) + stacked.shape[2:], stacked.dtype)
+    for k in range(params.part_count):
+        q = Params.from_buffer_copy(params)
+        q.part_index = k
+        m = part_row_map(q)
+        out[m[m >= 0]] = stacked[k][m >= 0]
+    return out
+
+
 def deinterleave_device(params, d_src, d_dst, elem_bytes, stream=None):
     _check(lib().rt_deinterleave_device(C.byref(params), d_src, d_dst, elem_bytes, stream))
 
