@@ -206,7 +206,8 @@ def main():
     rays_total, hits_total = float(tot[0].item()), float(tot[1].item())
 
     if rank == 0:
-        tests = cs["tests_primary"] + cs["tests_shadow"]
+        tests_ref = cs["tests_primary"] + cs["tests_shadow"]      # tests the reference's order needs (early exit)
+        tests = cs["tests_executed"]                              # tests run: runs whose box the line misses are skipped
         steps_ = cs["steps_primary"] + cs["steps_shadow"]
         nrays = cs["primary_rays"] + cs["hits"]
         f32 = tests * FLOP_TEST_F32 + steps_ * FLOP_STEP_F32 + nrays * FLOP_RAY_F32
@@ -240,12 +241,13 @@ def main():
             "frame_ms": {"build": round(ms_build, 4), "render": round(ms_render, 4), "device_total": round(ms_build + ms_render, 4)},
             "render_only_mrays": round(rays_local / t_render / 1e6, 2) if t_render > 0 else None,
             "roofline": {
-                "bound": "valu", "kernel": "k_render",
+                "bound": "valu", "kernel": "k_trace",
                 "achieved": round((f32 + f64) / t_render / 1e12, 4), "peak": round((f32 + f64) / t_peak / 1e12, 2), "unit": "TFLOP/s",
                 "frac": round(t_peak / t_render, 5),
                 "traffic": traffic,
-                "note": "algorithmic flops of rank 0's frame (early-exit step/test counts from the counting kernel: %d tests, %d steps, %d rays) over the "
-                        "mean k_render duration of the timed frames; peak = the same flops at 157.3 TF fp32 + 78.6 TF fp64" % (tests, steps_, nrays),
+                "note": "flops of the triangle tests k_trace executes (%d; the reference's early-exit order needs %d, the rest are skipped by the per-run "
+                        "box test), %d voxel steps and %d rays of rank 0's frame, over the mean k_classify+k_trace time of the timed frames; "
+                        "peak = the same flops at 157.3 TF fp32 + 78.6 TF fp64" % (tests, tests_ref, steps_, nrays),
             },
             "roofline_hbm": {
                 "bound": "hbm", "achieved": round(hbm_bytes / t_render / 1e9, 2), "peak": PEAK_HBM / 1e9, "unit": "GB/s",

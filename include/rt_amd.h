@@ -76,7 +76,8 @@ typedef struct rt_frame_stats {
     /* scheduling diagnostics of the counting kernel: rounds of the wavefront walk, voxel streams and lanes
      * served over all rounds, shader-clock cycles per traced tile (max, sum), traced tiles, most rounds in one tile */
     uint64_t sched_rounds, sched_streams, sched_lanes /* cycles in the step phase */, tile_cycles_max, tile_cycles_sum, tiles_traced, tile_rounds_max,
-        cycles_test /* cycles in the test phase */;
+        cycles_test /* cycles in the test phase */,
+        tests_executed /* triangle tests actually run: runs whose box the ray's line misses are skipped */;
 } rt_frame_stats;
 
 const char* rt_last_error(void);

@@ -45,7 +45,7 @@ class FrameStats(C.Structure):
         ("shadow_entering", C.c_uint64), ("steps_shadow", C.c_uint64), ("tests_shadow", C.c_uint64),
         ("sched_rounds", C.c_uint64), ("sched_streams", C.c_uint64), ("sched_lanes", C.c_uint64),
         ("tile_cycles_max", C.c_uint64), ("tile_cycles_sum", C.c_uint64), ("tiles_traced", C.c_uint64),
-        ("tile_rounds_max", C.c_uint64), ("cycles_test", C.c_uint64),
+        ("tile_rounds_max", C.c_uint64), ("cycles_test", C.c_uint64), ("tests_executed", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -68,8 +68,8 @@ struct rt_scene {
     DevBuf<float> d_mesh_color;
     DevBuf<RtGrid> d_grid;
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
-    DevBuf<float4> recs;
-    DevBuf<unsigned long long> counters;   // 16 frame counters + one 8-byte slot holding the two work-list words
+    DevBuf<float4> recs, blk_bounds;
+    DevBuf<unsigned long long> counters;   // 20 frame counters + one 8-byte slot holding the two work-list words
     DevBuf<uint32_t> tile_list;
     int n_cu = 0;
     uint32_t known_cells = 0;              // n_cells of the current triangle list once measured
@@ -97,7 +97,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         (void)hipSetDevice(s->device);
         s->v0.release(); s->v1.release(); s->v2.release(); s->d_mesh_color.release(); s->d_grid.release();
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
-        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->counters.release(); s->tile_list.release();
+        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
         for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
     }
@@ -290,7 +290,7 @@ static RtBuildDev build_args(rt_scene* s) {
     b.grid = s->d_grid.p;
     b.bounds_enc = s->bounds_enc.p;
     b.cell_count = s->cell_count.p; b.cell_start = s->cell_start.p; b.block_sums = s->block_sums.p; b.occupancy = s->occupancy.p;
-    b.ref_tri = s->ref_tri.p; b.ref_cell = s->ref_cell.p; b.recs = s->recs.p;
+    b.ref_tri = s->ref_tri.p; b.ref_cell = s->ref_cell.p; b.recs = s->recs.p; b.blk_bounds = s->blk_bounds.p;
     b.ref_cap = (uint32_t)s->ref_tri.cap;
     b.counters = s->counters.p;
     return b;
@@ -307,7 +307,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
-        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(17)))
+        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(21)))
         return rc;
     HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
     HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
@@ -344,7 +344,7 @@ static int build_grid_async(rt_scene* s, hipStream_t st) {
         s->known_cells = (uint32_t)g.n_cells;
         s->refs_known = true;
         size_t need = g.n_refs ? g.n_refs : 1;
-        if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->recs.ensure(3 * need))) return rc;
+        if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(2 * (need / 64 + 2)))) return rc;
     } else {
         HIP_TRY(rt_launch_build_phase1(build_args(s), st));
     }
@@ -420,13 +420,13 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         s->built[slot] = true;
     }
     HIP_TRY(hipEventRecord(s->ev[slot][1], st));
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 17 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 21 * sizeof(unsigned long long), st));
 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
     sd.mesh_color = s->d_mesh_color.p;
     sd.n_tris = (uint32_t)s->tri_mesh.size();
-    sd.grid = s->d_grid.p; sd.cell_start = s->cell_start.p; sd.occupancy = s->occupancy.p; sd.recs = s->recs.p;
+    sd.grid = s->d_grid.p; sd.cell_start = s->cell_start.p; sd.occupancy = s->occupancy.p; sd.recs = s->recs.p; sd.blk_bounds = s->blk_bounds.p;
     RtShade sh;
     for (int a = 0; a < 3; ++a) sh.light[a] = p->light_pos[a];
     sh.kd = p->kd; sh.ks = p->ks; sh.ka = p->ka; sh.spec_alpha = p->spec_alpha;
@@ -446,7 +446,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     {
         const size_t tiles = (size_t)((p->width + 7) / 8) * (size_t)((f.out_rows + 7) / 8);
         if ((rc = s->tile_list.ensure(tiles ? tiles : 1))) return rc;
-        wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 16);
+        wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 20);
         wk.tile_list = s->tile_list.p;
         // LDS for the occupancy bitmap: exact once the grid of this triangle list has been measured
         const uint32_t cells = s->refs_known ? s->known_cells : (uint32_t)RT_MAX_CELLS;
@@ -508,7 +508,7 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     HIP_TRY(hipEventElapsedTime(&out->ms_total, ev[0], ev[2]));
     if (!s->built[slot]) out->ms_build = 0.f;
     RtGrid g;
-    unsigned long long c[16];
+    unsigned long long c[20];
     HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
     for (int a = 0; a < 3; ++a) out->grid_n[a] = g.n[a];
@@ -530,7 +530,7 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     out->primary_entering = c[2]; out->steps_primary = c[3]; out->tests_primary = c[4];
     out->shadow_entering = c[5]; out->steps_shadow = c[6]; out->tests_shadow = c[7];
     out->sched_rounds = c[8]; out->sched_streams = c[9]; out->sched_lanes = c[10];
-    out->tile_cycles_max = c[11]; out->tile_cycles_sum = c[12]; out->tiles_traced = c[13]; out->tile_rounds_max = c[14]; out->cycles_test = c[15];
+    out->tile_cycles_max = c[11]; out->tile_cycles_sum = c[12]; out->tiles_traced = c[13]; out->tile_rounds_max = c[14]; out->cycles_test = c[15]; out->tests_executed = c[16];
     return RT_OK;
 }
 

@@ -353,6 +353,43 @@ __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
     }
 }
 
+// BLOCK BOUNDS: the axis-aligned box of the triangles of every aligned run of 64 records (lo.xyz + largest
+// absolute coordinate, hi.xyz). The render kernel skips a run when a ray's line clearly misses its box; the
+// reference would test those triangles and find that none passes.
+__global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
+    const uint32_t n_refs = b.grid->n_refs;
+    if (n_refs > b.ref_cap) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_blk = (n_refs + 63u) / 64u;
+    for (uint32_t blk = wave; blk < n_blk; blk += n_waves) {
+        const uint32_t p = blk * 64u + lane;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (p < n_refs) {
+            const uint32_t id = __float_as_uint(b.recs[3ull * p].w);
+            const float4 q0 = b.v0[id], q1 = b.v1[id], q2 = b.v2[id];
+            lo[0] = fminf(q0.x, fminf(q1.x, q2.x)); hi[0] = fmaxf(q0.x, fmaxf(q1.x, q2.x));
+            lo[1] = fminf(q0.y, fminf(q1.y, q2.y)); hi[1] = fmaxf(q0.y, fmaxf(q1.y, q2.y));
+            lo[2] = fminf(q0.z, fminf(q1.z, q2.z)); hi[2] = fmaxf(q0.z, fmaxf(q1.z, q2.z));
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+            }
+        }
+        if (lane == 0) {
+            float m = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) m = fmaxf(m, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+            b.blk_bounds[2ull * blk] = make_float4(lo[0], lo[1], lo[2], m);
+            b.blk_bounds[2ull * blk + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
+    }
+}
+
 hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st) {
     k_build_init<<<256, 256, 0, st>>>(b);
     if (b.n_tris) {
@@ -370,6 +407,7 @@ hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st) {
     if (b.n_tris == 0) return hipSuccess;
     k_scatter<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
     k_order_emit<<<1024, 256, 0, st>>>(b);
+    k_block_bounds<<<1024, 256, 0, st>>>(b);
     return hipGetLastError();
 }
 
@@ -401,6 +439,7 @@ hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32
 // ------------------------------------------------------------------------------------------------
 
 #define RT_WAVES_PER_BLOCK 4
+#define RT_CULL_MIN 96                              // voxels with at least this many triangles get the per-run box test
 #define RT_MAX_BITMAP_WORDS (RT_MAX_CELLS / 32)
 
 struct GridU {               // grid description held in scalar registers
@@ -425,7 +464,7 @@ struct Nearest {             // the reference's two globals, per ray (Serial/geo
 
 struct WalkCount {           // work counters of one ray (only maintained by the counting build of the kernel)
     uint32_t entered, steps, tests;
-    uint32_t rounds, slots, lanes;   // per wavefront (identical in every lane): scheduling rounds, streams served, lanes served
+    uint32_t rounds, slots, lanes;   // per wavefront (identical in every lane): scheduling rounds, voxel visits, triangle tests executed
     uint32_t cyc_step, cyc_test;     // shader cycles spent in the two phases
 };
 
@@ -671,84 +710,132 @@ __device__ __forceinline__ bool wave_walk(const GridU& g, const RtSceneDev& s, c
             unsigned long long members = __ballot(alive && cbeg == b);
             un &= ~members;
             if (COUNT) wc.slots += 1;
-            // first chunk
-            float4 n0, n1, n2;
-            {
-                const uint32_t k = b + lane;
-                const float4* r = s.recs + 3ull * (k < e ? k : b);
-                n0 = r[0]; n1 = r[1]; n2 = r[2];
-            }
-            for (uint32_t base = b; base < e; base += 64) {
-                const bool have = base + lane < e;
-                const TriRec t = unpack_rec(n0, n1, n2);
-                if (base + 64 < e) {       // prefetch the next chunk while this one is tested
-                    const uint32_t k = base + 64 + lane;
-                    const float4* r = s.recs + 3ull * (k < e ? k : b);
+            // The voxel's records are visited in runs of 64 (lane = record). Crowded voxels use runs aligned to
+            // multiples of 64 in the record array, which is what the per-run boxes describe; small voxels start at
+            // their first record and usually fit one run.
+            const bool cull = (e - b) >= RT_CULL_MIN;
+            const uint32_t org = cull ? (b & ~63u) : b;
+            for (uint32_t r0 = org; r0 < e; r0 += 64u * 64u) {
+                const uint32_t runs_left = (e - r0 + 63u) >> 6;
+                const uint32_t n_run = runs_left < 64u ? runs_left : 64u;                     // runs in this pass
+                const uint32_t g0 = r0 >> 6;                                                  // first box (aligned case)
+                // ---- which runs does each ray need? Crowded voxels only: lane = run, its box against the ray's line.
+                unsigned long long need_any = (n_run == 64u) ? ~0ull : ((1ull << n_run) - 1ull);
+                unsigned long long my_need = need_any;           // lane i: runs ray i has to test
+                if (cull) {
+                    double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0}, bm = 0;
+                    if ((uint32_t)lane < n_run) {
+                        const float4 q0 = s.blk_bounds[2ull * (g0 + lane)], q1 = s.blk_bounds[2ull * (g0 + lane) + 1];
+                        blo[0] = q0.x; blo[1] = q0.y; blo[2] = q0.z; bm = q0.w;
+                        bhi[0] = q1.x; bhi[1] = q1.y; bhi[2] = q1.z;
+                    }
+                    need_any = 0;
+                    unsigned long long lm = members;
+                    while (lm) {
+                        const int i = __ffsll((long long)lm) - 1;
+                        lm &= lm - 1;
+                        const double ro[3] = {(double)bcast_f32(ox, i), (double)bcast_f32(oy, i), (double)bcast_f32(oz, i)};
+                        const double rd[3] = {bcast_f64(ddx, i), bcast_f64(ddy, i), bcast_f64(ddz, i)};
+                        // slab test of the whole line against the box grown by a margin far above the rounding of
+                        // this test and of the reference's double-precision triangle test; NaNs keep the run
+                        const double mg = 1e-6 * (bm + fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2])) + 1e-30;
+                        double t0 = -INFINITY, t1 = INFINITY;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const double inv = 1.0 / rd[a];
+                            const double ta = ((blo[a] - mg) - ro[a]) * inv, tb = ((bhi[a] + mg) - ro[a]) * inv;
+                            t0 = fmax(t0, fmin(ta, tb));
+                            t1 = fmin(t1, fmax(ta, tb));
+                        }
+                        const unsigned long long m = __ballot((uint32_t)lane < n_run && !(t0 > t1));
+                        need_any |= m;
+                        if (lane == i) my_need = m;
+                    }
+                }
+                // ---- the needed runs, in ascending order; the next needed run is prefetched during the tests
+                float4 n0, n1, n2;
+                if (need_any) {
+                    const uint32_t p = r0 + ((uint32_t)__ffsll((long long)need_any) - 1u) * 64u + lane;
+                    const float4* r = s.recs + 3ull * ((p >= b && p < e) ? p : b);
                     n0 = r[0]; n1 = r[1]; n2 = r[2];
                 }
-                // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
-                double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
-                if (SHARED_ORIGIN) {
-                    sx = t.v0x - ox; sy = t.v0y - oy; sz = t.v0z - oz;        // float subtractions, then widened
-                    p_e2s = t.e2y * sz - sy * t.e2z;
-                    p_e1s = t.e1y * sz - sy * t.e1z;
-                }
-                unsigned long long lm = members;
-                while (lm) {
-                    const int i = __ffsll((long long)lm) - 1;
-                    lm &= lm - 1;
-                    const double rdx = bcast_f64(ddx, i), rdy = bcast_f64(ddy, i), rdz = bcast_f64(ddz, i);
-                    if (!SHARED_ORIGIN) {
-                        const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
-                        sx = t.v0x - rox; sy = t.v0y - roy; sz = t.v0z - roz;
+                while (need_any) {
+                    const int k = __ffsll((long long)need_any) - 1;
+                    need_any &= need_any - 1;
+                    const uint32_t base = r0 + (uint32_t)k * 64u;
+                    const bool have = base + lane >= b && base + lane < e;
+                    const TriRec t = unpack_rec(n0, n1, n2);
+                    if (COUNT) wc.lanes += (uint32_t)__popcll(__ballot(have)) * (uint32_t)__popcll(members & __ballot((my_need >> k) & 1ull));
+                    if (need_any) {
+                        const uint32_t p = r0 + ((uint32_t)__ffsll((long long)need_any) - 1u) * 64u + lane;
+                        const float4* r = s.recs + 3ull * ((p >= b && p < e) ? p : b);
+                        n0 = r[0]; n1 = r[1]; n2 = r[2];
+                    }
+                    // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
+                    double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
+                    if (SHARED_ORIGIN) {
+                        sx = t.v0x - ox; sy = t.v0y - oy; sz = t.v0z - oz;        // float subtractions, then widened
                         p_e2s = t.e2y * sz - sy * t.e2z;
                         p_e1s = t.e1y * sz - sy * t.e1z;
                     }
-                    const double p_e2d = t.e2y * rdz - rdy * t.e2z;
-                    const double p_e1d = t.e1y * rdz - rdy * t.e1z;
-                    const double p_sd = sy * rdz - rdy * sz;
-                    const double A = t.e1x * p_e2d - t.e2x * p_e1d + rdx * t.m12;
-                    const double bnum = sx * p_e2d - t.e2x * p_sd - rdx * p_e2s;
-                    const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
-                    const bool pos = (A > 0.0) && (bnum > 0.0) && (gnum > 0.0);
-                    const bool neg = (A < 0.0) && (bnum < 0.0) && (gnum < 0.0);
-                    bool pass = false;
-                    double tt = 0.0;
-                    if (have && (pos || neg) && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12))) {
-                        const double beta = bnum / A;
-                        const double gamma = gnum / A;
-                        if (beta > 0 && gamma > 0 && beta + gamma < 1) {
-                            pass = true;
-                            if (!ANY_HIT) {
-                                const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
-                                tt = tnum / A;
+                    unsigned long long lm = members & __ballot((my_need >> k) & 1ull);
+                    while (lm) {
+                        const int i = __ffsll((long long)lm) - 1;
+                        lm &= lm - 1;
+                        const double rdx = bcast_f64(ddx, i), rdy = bcast_f64(ddy, i), rdz = bcast_f64(ddz, i);
+                        if (!SHARED_ORIGIN) {
+                            const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
+                            sx = t.v0x - rox; sy = t.v0y - roy; sz = t.v0z - roz;
+                            p_e2s = t.e2y * sz - sy * t.e2z;
+                            p_e1s = t.e1y * sz - sy * t.e1z;
+                        }
+                        const double p_e2d = t.e2y * rdz - rdy * t.e2z;
+                        const double p_e1d = t.e1y * rdz - rdy * t.e1z;
+                        const double p_sd = sy * rdz - rdy * sz;
+                        const double A = t.e1x * p_e2d - t.e2x * p_e1d + rdx * t.m12;
+                        const double bnum = sx * p_e2d - t.e2x * p_sd - rdx * p_e2s;
+                        const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
+                        const bool pos = (A > 0.0) && (bnum > 0.0) && (gnum > 0.0);
+                        const bool neg = (A < 0.0) && (bnum < 0.0) && (gnum < 0.0);
+                        bool pass = false;
+                        double tt = 0.0;
+                        if (have && (pos || neg) && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12))) {
+                            const double beta = bnum / A;
+                            const double gamma = gnum / A;
+                            if (beta > 0 && gamma > 0 && beta + gamma < 1) {
+                                pass = true;
+                                if (!ANY_HIT) {
+                                    const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
+                                    tt = tnum / A;
+                                }
                             }
                         }
-                    }
-                    unsigned long long pm = __ballot(pass);
-                    if (pm) {
-                        if (ANY_HIT) {
-                            members &= ~(1ull << i);
-                            if (lane == i) {
-                                hit = true; alive = false;
-                                if (COUNT) wc.tests -= e - (base + (uint32_t)__ffsll((long long)pm));   // tests the reference order skips
-                            }
-                        } else {
-                            if (lane == i) hit = true;
-                            // apply the passing triangles in ascending lane order = ascending triangle order
-                            while (pm) {
-                                const int pl = __ffsll((long long)pm) - 1;
-                                pm &= pm - 1;
-                                const double t_p = bcast_f64(tt, pl);
-                                const int id_p = __builtin_amdgcn_readlane((int)t.id, pl);
+                        unsigned long long pm = __ballot(pass);
+                        if (pm) {
+                            if (ANY_HIT) {
+                                members &= ~(1ull << i);
                                 if (lane == i) {
-                                    if (t_p < (double)st.t) {
-                                        if (!use_eps || t_p > (double)eps) { st.t = (float)t_p; st.id = id_p; }
+                                    hit = true; alive = false;
+                                    if (COUNT) wc.tests -= e - (base + (uint32_t)__ffsll((long long)pm));   // tests the reference order skips
+                                }
+                            } else {
+                                if (lane == i) hit = true;
+                                // apply the passing triangles in ascending lane order = ascending triangle order
+                                while (pm) {
+                                    const int pl = __ffsll((long long)pm) - 1;
+                                    pm &= pm - 1;
+                                    const double t_p = bcast_f64(tt, pl);
+                                    const int id_p = __builtin_amdgcn_readlane((int)t.id, pl);
+                                    if (lane == i) {
+                                        if (t_p < (double)st.t) {
+                                            if (!use_eps || t_p > (double)eps) { st.t = (float)t_p; st.id = id_p; }
+                                        }
                                     }
                                 }
                             }
                         }
                     }
+                    if (ANY_HIT && !members) break;
                 }
                 if (ANY_HIT && !members) break;
             }
@@ -876,6 +963,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s,
                     atomicAdd(&o.counters[12], cyc);
                     atomicAdd(&o.counters[13], 1ull);
                     atomicMax(&o.counters[14], (unsigned long long)(wp.rounds + ws.rounds));
+                    atomicAdd(&o.counters[16], (unsigned long long)wp.lanes + (unsigned long long)ws.lanes);
                 }
             }
         }
