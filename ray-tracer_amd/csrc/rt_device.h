@@ -41,6 +41,7 @@ struct RtFrame {
     float early_slack;
     int32_t count_work;           // 1 = the kernel also counts voxel steps and triangle tests
     int32_t unit_shift;           // -1 = choose per frame; 0/1/2 = whole, half or quarter tiles per wavefront
+    int32_t dequeue_batch;        // work units a wavefront takes from the queue per atomic
 };
 
 // Device pointers of one scene.
@@ -70,6 +71,7 @@ struct RtRenderWork {
     uint32_t* tile_list;          // capacity = tiles of the frame
     int32_t bitmap_words;         // LDS words reserved for the occupancy bitmap (>= ceil(n_cells / 32))
     int32_t n_cu, blocks_per_cu;
+    int32_t tx0, ntx, tb0, ntb;   // tile columns x local bands that may see the grid (conservative); the rest stays background
 };
 
 // Build-time scratch.

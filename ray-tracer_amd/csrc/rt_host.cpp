@@ -73,6 +73,7 @@ struct rt_scene {
     DevBuf<uint32_t> tile_list;
     int n_cu = 0;
     uint32_t known_cells = 0;              // n_cells of the current triangle list once measured
+    RtGrid h_grid;                         // grid description of the current triangle list once measured
     // outputs owned by the host-buffer entry point
     DevBuf<float> o_rgb;
     DevBuf<uint8_t> o_u8;
@@ -342,6 +343,7 @@ static int build_grid_async(rt_scene* s, hipStream_t st) {
         HIP_TRY(hipStreamSynchronize(st));
         s->known_refs = g.n_refs;
         s->known_cells = (uint32_t)g.n_cells;
+        s->h_grid = g;
         s->refs_known = true;
         size_t need = g.n_refs ? g.n_refs : 1;
         if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(2 * (need / 64 + 2)))) return rc;
@@ -406,6 +408,36 @@ static int check_params(const rt_params* p) {
     return RT_OK;
 }
 
+// Conservative screen rectangle (in 8x8 tiles of the full frame) of the pixels whose primary rays can enter the grid
+// bounds: the bounding rectangle of the 8 projected corners, widened by 2 pixels. The per-pixel bounds test still
+// decides exactly; this only limits where it has to run. Falls back to the whole frame when a corner is not
+// safely in front of the camera.
+static void grid_tile_rect(const RtCamera& c, const RtGrid& g, int W, int H, int& tx0, int& tx1, int& ty0, int& ty1) {
+    const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+    tx0 = 0; tx1 = tiles_x - 1; ty0 = 0; ty1 = tiles_y - 1;
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int k = 0; k < 8; ++k) {
+        const double P[3] = {(k & 1) ? g.hi[0] : g.lo[0], (k & 2) ? g.hi[1] : g.lo[1], (k & 4) ? g.hi[2] : g.lo[2]};
+        const double q[3] = {P[0] - c.pos[0], P[1] - c.pos[1], P[2] - c.pos[2]};
+        const double depth = -(q[0] * c.w[0] + q[1] * c.w[1] + q[2] * c.w[2]);
+        const double len = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        if (!(depth > 1e-3 * len) || !(len < 1e30)) return;          // behind / beside the camera, or not finite
+        const double a = (q[0] * c.u[0] + q[1] * c.u[1] + q[2] * c.u[2]) / depth * c.focal_distance;
+        const double b = (q[0] * c.v[0] + q[1] * c.v[1] + q[2] * c.v[2]) / depth * c.focal_distance;
+        const double x = a * W / c.aspect + W / 2.0 - 0.5, y = b * H + H / 2.0 - 0.5;
+        if (!(x == x) || !(y == y)) return;
+        xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax;
+        ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax;
+    }
+    xmin = floor(xmin) - 2; xmax = ceil(xmax) + 2; ymin = floor(ymin) - 2; ymax = ceil(ymax) + 2;
+    if (xmax < 0 || ymax < 0 || xmin > W - 1 || ymin > H - 1) { tx1 = -1; ty1 = -1; return; }     // off screen
+    if (xmin < 0) xmin = 0;
+    if (ymin < 0) ymin = 0;
+    if (xmax > W - 1) xmax = W - 1;
+    if (ymax > H - 1) ymax = H - 1;
+    tx0 = (int)xmin / 8; tx1 = (int)xmax / 8; ty0 = (int)ymin / 8; ty1 = (int)ymax / 8;
+}
+
 extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_grid, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id, void* stream) {
     if (!s) return set_err(RT_ERR_INVALID, "rt_render_device: NULL scene");
     int rc = check_params(p);
@@ -439,11 +471,29 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.early_slack = 0.f;
     f.count_work = s->count_work ? 1 : 0;
     { const char* e = getenv("RT_UNIT_SHIFT"); f.unit_shift = e ? atoi(e) : -1; }
+    { const char* e = getenv("RT_DEQUEUE_BATCH"); f.dequeue_batch = e ? atoi(e) : 1; if (f.dequeue_batch < 1) f.dequeue_batch = 1; }
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;
+    // background everywhere first: black, no hit
+    const size_t out_px = (size_t)p->width * (size_t)f.out_rows;
+    if (o.rgb_f32) HIP_TRY(hipMemsetAsync(o.rgb_f32, 0, out_px * 3 * sizeof(float), st));
+    if (o.rgb_u8) HIP_TRY(hipMemsetAsync(o.rgb_u8, 0, out_px * 3, st));
+    if (o.hit_id) HIP_TRY(hipMemsetAsync(o.hit_id, 0xff, out_px * sizeof(int32_t), st));
+    const RtCamera cam = make_camera(p);
     RtRenderWork wk;
     {
+        // tiles that can see the grid: full-frame tile rows ty0..ty1 -> local bands of this part
+        int tx0, tx1, ty0, ty1;
+        if (s->refs_known) grid_tile_rect(cam, s->h_grid, p->width, p->height, tx0, tx1, ty0, ty1);
+        else { tx0 = 0; tx1 = (p->width + 7) / 8 - 1; ty0 = 0; ty1 = (p->height + 7) / 8 - 1; }
+        const int pc = p->part_count, pi = p->part_index;
+        int lb0 = (ty0 - pi + pc - 1) / pc;
+        if (ty0 < pi) lb0 = 0;
+        const int lb1 = (ty1 >= pi) ? (ty1 - pi) / pc : -1;
+        wk.tx0 = tx0; wk.ntx = tx1 - tx0 + 1; wk.tb0 = lb0; wk.ntb = lb1 - lb0 + 1;
+        if (wk.ntx < 0) wk.ntx = 0;
+        if (wk.ntb < 0) wk.ntb = 0;
         const size_t tiles = (size_t)((p->width + 7) / 8) * (size_t)((f.out_rows + 7) / 8);
         if ((rc = s->tile_list.ensure(tiles ? tiles : 1))) return rc;
         wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 20);
@@ -458,7 +508,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         wk.blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
 
     }
-    HIP_TRY(rt_launch_render(sd, make_camera(p), sh, f, o, wk, st));
+    HIP_TRY(rt_launch_render(sd, cam, sh, f, o, wk, st));
     HIP_TRY(hipEventRecord(s->ev[slot][2], st));
     s->frames++;
     s->last_stream = st;

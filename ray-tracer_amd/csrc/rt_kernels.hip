@@ -529,24 +529,51 @@ __device__ __forceinline__ void write_pixel(const RtFrame& f, const RtOutputs& o
 }
 
 // work[0] = number of listed tiles, work[1] = dequeue head; both zeroed by the host before each frame.
-__global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, RtFrame f, RtOutputs o, uint32_t* work, uint32_t* tile_list,
-                                                  int n_tiles) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
-    int x, y_local, y;
-    tile_pixel(f, tile, lane, x, y_local, y);
-    bool enters = false;
-    if (x < f.width && y < f.height && s.n_tris > 0) {
-        const GridU g = load_grid(s.grid);
-        float dx, dy, dz, rayT;
-        primary_ray(cam, f, x, y, dx, dy, dz);
-        enters = grid_entry(g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, rayT);
+// Runs over the tile rectangle [tx0, tx0+ntx) x [tb0, tb0+ntb) (tile columns x local bands) that can contain rays
+// entering the grid; the host has cleared the outputs to the background, so tiles that are not listed need no write.
+#define RT_CLS_TILES_PER_WAVE 4
+
+__global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, RtFrame f, uint32_t* work, uint32_t* tile_list, int tx0,
+                                                  int ntx, int tb0, int ntb) {
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ uint32_t block_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tiles_x = (f.width + RT_TILE - 1) / RT_TILE;
+    const GridU g = load_grid(s.grid);
+    // every wavefront tests RT_CLS_TILES_PER_WAVE tiles; the tiles to list are appended with ONE atomic per block
+    // (a single counter takes only some tens of atomics per microsecond)
+    int mine[RT_CLS_TILES_PER_WAVE];
+    uint32_t n_mine = 0;
+#pragma unroll
+    for (int k = 0; k < RT_CLS_TILES_PER_WAVE; ++k) {
+        const int t = (blockIdx.x * 4 + wv) * RT_CLS_TILES_PER_WAVE + k;
+        mine[k] = -1;
+        if (t < ntx * ntb) {
+            const int tile = (tb0 + t / ntx) * tiles_x + tx0 + t % ntx;
+            int x, y_local, y;
+            tile_pixel(f, tile, lane, x, y_local, y);
+            bool enters = false;
+            if (x < f.width && y < f.height) {
+                float dx, dy, dz, rayT;
+                primary_ray(cam, f, x, y, dx, dy, dz);
+                enters = grid_entry(g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, rayT);
+            }
+            if (__ballot(enters)) { mine[k] = tile; ++n_mine; }
+        }
     }
-    if (__ballot(enters)) {
-        if (lane == 0) tile_list[atomicAdd(&work[0], 1u)] = (uint32_t)tile;
-    } else {
-        write_pixel(f, o, x, y_local, 0.f, 0.f, 0.f, -1);
+    if (lane == 0) wave_cnt[wv] = n_mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        block_base = total ? atomicAdd(&work[0], total) : 0u;
+    }
+    __syncthreads();
+    if (lane == 0 && n_mine) {
+        uint32_t pos = block_base;
+        for (int k = 0; k < wv; ++k) pos += wave_cnt[k];
+#pragma unroll
+        for (int k = 0; k < RT_CLS_TILES_PER_WAVE; ++k)
+            if (mine[k] >= 0) tile_list[pos++] = (uint32_t)mine[k];
     }
 }
 
@@ -684,6 +711,7 @@ __device__ __forceinline__ bool wave_walk(const GridU& g, const RtSceneDev& s, c
     bool hit = false;
     bool first = true;
     const double ddx = dx, ddy = dy, ddz = dz;
+    const double idx = 1.0 / ddx, idy = 1.0 / ddy, idz = 1.0 / ddz;     // for the per-run box test
     for (;;) {
         // ---- STEP: on to the next occupied voxel
         const long long t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -723,27 +751,37 @@ __device__ __forceinline__ bool wave_walk(const GridU& g, const RtSceneDev& s, c
                 unsigned long long need_any = (n_run == 64u) ? ~0ull : ((1ull << n_run) - 1ull);
                 unsigned long long my_need = need_any;           // lane i: runs ray i has to test
                 if (cull) {
+                    // lane = run: its box, grown by a margin far above the rounding of this test and of the reference's
+                    // double-precision triangle test, against the whole line of each ray (slab test); NaNs keep the run
                     double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0}, bm = 0;
                     if ((uint32_t)lane < n_run) {
                         const float4 q0 = s.blk_bounds[2ull * (g0 + lane)], q1 = s.blk_bounds[2ull * (g0 + lane) + 1];
                         blo[0] = q0.x; blo[1] = q0.y; blo[2] = q0.z; bm = q0.w;
                         bhi[0] = q1.x; bhi[1] = q1.y; bhi[2] = q1.z;
                     }
+                    if (SHARED_ORIGIN) {      // box relative to the common origin, once per voxel
+                        const double mg = 1e-6 * (bm + fabs((double)ox) + fabs((double)oy) + fabs((double)oz)) + 1e-30;
+                        const double ro[3] = {(double)ox, (double)oy, (double)oz};
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) { blo[a] = (blo[a] - mg) - ro[a]; bhi[a] = (bhi[a] + mg) - ro[a]; }
+                    }
                     need_any = 0;
                     unsigned long long lm = members;
                     while (lm) {
                         const int i = __ffsll((long long)lm) - 1;
                         lm &= lm - 1;
-                        const double ro[3] = {(double)bcast_f32(ox, i), (double)bcast_f32(oy, i), (double)bcast_f32(oz, i)};
-                        const double rd[3] = {bcast_f64(ddx, i), bcast_f64(ddy, i), bcast_f64(ddz, i)};
-                        // slab test of the whole line against the box grown by a margin far above the rounding of
-                        // this test and of the reference's double-precision triangle test; NaNs keep the run
-                        const double mg = 1e-6 * (bm + fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2])) + 1e-30;
+                        const double ri[3] = {bcast_f64(idx, i), bcast_f64(idy, i), bcast_f64(idz, i)};
+                        double lo_[3] = {blo[0], blo[1], blo[2]}, hi_[3] = {bhi[0], bhi[1], bhi[2]};
+                        if (!SHARED_ORIGIN) {
+                            const double ro[3] = {(double)bcast_f32(ox, i), (double)bcast_f32(oy, i), (double)bcast_f32(oz, i)};
+                            const double mg = 1e-6 * (bm + fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2])) + 1e-30;
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) { lo_[a] = (blo[a] - mg) - ro[a]; hi_[a] = (bhi[a] + mg) - ro[a]; }
+                        }
                         double t0 = -INFINITY, t1 = INFINITY;
 #pragma unroll
                         for (int a = 0; a < 3; ++a) {
-                            const double inv = 1.0 / rd[a];
-                            const double ta = ((blo[a] - mg) - ro[a]) * inv, tb = ((bhi[a] + mg) - ro[a]) * inv;
+                            const double ta = lo_[a] * ri[a], tb = hi_[a] * ri[a];
                             t0 = fmax(t0, fmin(ta, tb));
                             t1 = fmin(t1, fmax(ta, tb));
                         }
@@ -867,10 +905,14 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s,
     const uint32_t n_waves = gridDim.x * RT_WAVES_PER_BLOCK;
     const int ushift = f.unit_shift >= 0 ? f.unit_shift : ((n_listed >= 24u * n_waves) ? 0 : ((n_listed >= 12u * n_waves) ? 1 : 2));
     const uint32_t n_units = n_listed << ushift;
-    for (;;) {
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(&work[1], 1u);
-        slot = __builtin_amdgcn_readfirstlane(slot);
+    const uint32_t batch = (uint32_t)f.dequeue_batch;
+    uint32_t slot = 0, slot_end = 0;
+    for (;; ++slot) {
+        if (slot >= slot_end) {         // take the next `batch` units with one atomic
+            if (lane == 0) slot = atomicAdd(&work[1], batch);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            slot_end = slot + batch;
+        }
         if (slot >= n_units) break;
         const int tile = (int)tile_list[slot >> ushift];
         const int sub = (int)(slot & ((1u << ushift) - 1u));
@@ -976,7 +1018,8 @@ hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, R
     const int tiles_y = (f.out_rows + RT_TILE - 1) / RT_TILE;
     const int tiles = tiles_x * tiles_y;
     if (tiles <= 0) return hipSuccess;
-    k_classify<<<(tiles + 3) / 4, 256, 0, st>>>(s, cam, f, o, wk.work, wk.tile_list, tiles);
+    const int n_cls = wk.ntx * wk.ntb;
+    if (n_cls > 0 && s.n_tris > 0) k_classify<<<(n_cls + 4 * RT_CLS_TILES_PER_WAVE - 1) / (4 * RT_CLS_TILES_PER_WAVE), 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
     const size_t lds = rt_trace_lds_bytes(wk.bitmap_words);
     int blocks = wk.n_cu * wk.blocks_per_cu;
     const int max_useful = (tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK;
