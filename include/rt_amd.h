@@ -128,6 +128,9 @@ int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out);
  * frames is kept, so a benchmark can time a whole run without synchronising inside it). Counters are
  * those of the last frame. */
 int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stats* out);
+/* Diagnostics: shader cycles of every work unit of the last counting frame, in queue order (0 = unused slot).
+ * Returns the number of entries copied. */
+int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n);
 /* Work accounting: when enabled, frames also count voxel steps and triangle tests per ray class. */
 int rt_scene_set_counting(rt_scene* s, int32_t enable);
 

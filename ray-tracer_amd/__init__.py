@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB", os.path.join(_HERE, "librt_amd.so"))   # override: A/B runs of two builds
 
 RT_WALK_EARLY, RT_WALK_FULL = 0, 1
 RT_BAND_ROWS = 8
@@ -61,7 +61,7 @@ EXPORTS = [
     "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
-    "rt_render_device", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting",
+    "rt_render_device", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_unit_costs",
     "rt_deinterleave_device",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
@@ -109,6 +109,8 @@ def lib():
     L.rt_scene_last_stats.argtypes = [vp, vp]
     L.rt_scene_stats_at.argtypes = [vp, i32, vp]
     L.rt_scene_set_counting.argtypes = [vp, i32]
+    if hasattr(L, "rt_scene_unit_costs"):
+        L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
     L.rt_deinterleave_device.argtypes = [vp, vp, vp, i32, vp]
     L.rt_write_ppm.argtypes = [C.c_char_p, vp, i32, i32]
     L.rt_write_ppm_u8.argtypes = [C.c_char_p, vp, i32, i32]
@@ -223,6 +225,11 @@ class Scene:
         st = FrameStats()
         _check(lib().rt_scene_stats_at(self.h, frames_back, C.byref(st)))
         return st.as_dict()
+
+    def unit_costs(self, n):
+        out = np.zeros(n, np.uint32)
+        k = _check(lib().rt_scene_unit_costs(self.h, out.ctypes.data, n))
+        return out[:k]
 
     def set_counting(self, enable):
         _check(lib().rt_scene_set_counting(self.h, int(bool(enable))))

@@ -42,6 +42,7 @@ struct RtFrame {
     int32_t count_work;           // 1 = the kernel also counts voxel steps and triangle tests
     int32_t unit_shift;           // -1 = choose per frame; 0/1/2 = whole, half or quarter tiles per wavefront
     int32_t dequeue_batch;        // work units a wavefront takes from the queue per atomic
+    int32_t cull_min;             // voxels with at least this many triangles get the per-run box test
 };
 
 // Device pointers of one scene.
@@ -62,6 +63,7 @@ struct RtOutputs {
     float* rgb_f32;
     uint8_t* rgb_u8;
     int32_t* hit_id;
+    uint32_t* unit_cost;          // counting build only: shader cycles of every work unit, in queue order (may be NULL)
     unsigned long long* counters; // [0] hits, [1] shadowed, [2..4] primary entered/steps/tests, [5..7] shadow entered/steps/tests
 };
 

@@ -70,7 +70,7 @@ struct rt_scene {
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
     DevBuf<float4> recs, blk_bounds;
     DevBuf<unsigned long long> counters;   // 20 frame counters + one 8-byte slot holding the two work-list words
-    DevBuf<uint32_t> tile_list;
+    DevBuf<uint32_t> tile_list, unit_cost;
     int n_cu = 0;
     uint32_t known_cells = 0;              // n_cells of the current triangle list once measured
     RtGrid h_grid;                         // grid description of the current triangle list once measured
@@ -98,7 +98,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         (void)hipSetDevice(s->device);
         s->v0.release(); s->v1.release(); s->v2.release(); s->d_mesh_color.release(); s->d_grid.release();
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
-        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release();
+        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
         for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
     }
@@ -471,10 +471,12 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.early_slack = 0.f;
     f.count_work = s->count_work ? 1 : 0;
     { const char* e = getenv("RT_UNIT_SHIFT"); f.unit_shift = e ? atoi(e) : -1; }
+    { const char* e = getenv("RT_CULL_MIN"); f.cull_min = e ? atoi(e) : 96; }
     { const char* e = getenv("RT_DEQUEUE_BATCH"); f.dequeue_batch = e ? atoi(e) : 1; if (f.dequeue_batch < 1) f.dequeue_batch = 1; }
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;
+    o.unit_cost = nullptr;
     // background everywhere first: black, no hit
     const size_t out_px = (size_t)p->width * (size_t)f.out_rows;
     if (o.rgb_f32) HIP_TRY(hipMemsetAsync(o.rgb_f32, 0, out_px * 3 * sizeof(float), st));
@@ -496,6 +498,11 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         if (wk.ntb < 0) wk.ntb = 0;
         const size_t tiles = (size_t)((p->width + 7) / 8) * (size_t)((f.out_rows + 7) / 8);
         if ((rc = s->tile_list.ensure(tiles ? tiles : 1))) return rc;
+        if (s->count_work) {
+            if ((rc = s->unit_cost.ensure((tiles ? tiles : 1) * 64))) return rc;
+            HIP_TRY(hipMemsetAsync(s->unit_cost.p, 0, (tiles ? tiles : 1) * 64 * sizeof(uint32_t), st));
+            o.unit_cost = s->unit_cost.p;
+        }
         wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 20);
         wk.tile_list = s->tile_list.p;
         // LDS for the occupancy bitmap: exact once the grid of this triangle list has been measured
@@ -544,6 +551,15 @@ extern "C" int rt_scene_set_counting(rt_scene* s, int32_t enable) {
 }
 
 extern "C" int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out) { return rt_scene_stats_at(s, 0, out); }
+
+extern "C" int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n) {
+    if (!s || !out || n < 0) return set_err(RT_ERR_INVALID, "rt_scene_unit_costs: bad argument");
+    if (!s->unit_cost.p) return set_err(RT_ERR_INVALID, "no counting frame rendered yet");
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t k = (size_t)n < s->unit_cost.cap ? (size_t)n : s->unit_cost.cap;
+    HIP_TRY(hipMemcpy(out, s->unit_cost.p, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return (int)k;
+}
 
 extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stats* out) {
     if (!s || !out) return set_err(RT_ERR_INVALID, "rt_scene_stats_at: bad argument");

@@ -439,7 +439,7 @@ hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32
 // ------------------------------------------------------------------------------------------------
 
 #define RT_WAVES_PER_BLOCK 4
-#define RT_CULL_MIN 96                              // voxels with at least this many triangles get the per-run box test
+#define RT_CULL_LANE_RUNS 12                        // voxels with more 64-record runs than this are culled run-parallel
 #define RT_MAX_BITMAP_WORDS (RT_MAX_CELLS / 32)
 
 struct GridU {               // grid description held in scalar registers
@@ -581,58 +581,68 @@ __global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, Rt
 // the linear voxel index, its increment per axis and the number of steps left before the ray leaves the grid
 // along each axis (Pos == Out after left+1 steps).
 struct Dda {
-    float next[3], delta[3];
-    int left[3];
-    int cstep[3];
+    // scalars on purpose: with arrays the compiler turns the per-axis selects below into indexed scratch loads
+    float next0, next1, next2, delta0, delta1, delta2;
+    int left0, left1, left2;
+    int cstep0, cstep1, cstep2;
     int cell;
 };
 
-__device__ __forceinline__ void dda_setup(Dda& w, const GridU& g, float ox, float oy, float oz, float dx, float dy, float dz, float rayT) {
-    const float gi[3] = {ox + dx * rayT, oy + dy * rayT, oz + dz * rayT};
-    const float d[3] = {dx, dy, dz};
-    const int stride[3] = {1, g.n[0], g.n[0] * g.n[1]};
-    w.cell = 0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const int pos = pos_to_voxel(gi[a], g.lo[a], g.inv_width[a], g.n[a]);
-        if (d[a] >= 0) {
-            w.next[a] = rayT + ((g.lo[a] + (float)(pos + 1) * g.width[a]) - gi[a]) / d[a];
-            w.delta[a] = g.width[a] / d[a];
-            w.left[a] = g.n[a] - 1 - pos;
-            w.cstep[a] = stride[a];
-        } else {
-            w.next[a] = rayT + ((g.lo[a] + (float)pos * g.width[a]) - gi[a]) / d[a];
-            w.delta[a] = -g.width[a] / d[a];
-            w.left[a] = pos;
-            w.cstep[a] = -stride[a];
-        }
-        w.cell += pos * stride[a];
+__device__ __forceinline__ void dda_axis(const GridU& g, int a, int stride, float o, float d, float rayT, float& next, float& delta,
+                                         int& left, int& cstep, int& cell) {
+    const float gi = o + d * rayT;
+    const int pos = pos_to_voxel(gi, g.lo[a], g.inv_width[a], g.n[a]);
+    if (d >= 0) {
+        next = rayT + ((g.lo[a] + (float)(pos + 1) * g.width[a]) - gi) / d;
+        delta = g.width[a] / d;
+        left = g.n[a] - 1 - pos;
+        cstep = stride;
+    } else {
+        next = rayT + ((g.lo[a] + (float)pos * g.width[a]) - gi) / d;
+        delta = -g.width[a] / d;
+        left = pos;
+        cstep = -stride;
     }
+    cell += pos * stride;
+}
+
+__device__ __forceinline__ void dda_setup(Dda& w, const GridU& g, float ox, float oy, float oz, float dx, float dy, float dz, float rayT) {
+    w.cell = 0;
+    dda_axis(g, 0, 1, ox, dx, rayT, w.next0, w.delta0, w.left0, w.cstep0, w.cell);
+    dda_axis(g, 1, g.n[0], oy, dy, rayT, w.next1, w.delta1, w.left1, w.cstep1, w.cell);
+    dda_axis(g, 2, g.n[0] * g.n[1], oz, dz, rayT, w.next2, w.delta2, w.left2, w.cstep2, w.cell);
 }
 
 // One step of the walk loop, Serial/grid.h:216-227, plus the early-exit rule. Returns false when the ray is done.
 // stepAxis comes from the 3-bit compare table {2,1,2,1,2,2,0,0}: axis 0 iff next0 < next1 and next0 < next2,
 // axis 1 iff not (next0 < next1) and next1 < next2, else axis 2. Written without branches on the axis.
 __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t, float slack) {
-    const bool c01 = w.next[0] < w.next[1], c02 = w.next[0] < w.next[2], c12 = w.next[1] < w.next[2];
+    // Copies that the optimiser has to treat as register values: without them it rewrites the selects below as one
+    // load from a selected address, which pins the whole state in scratch memory.
+    float n0 = w.next0, n1 = w.next1, n2 = w.next2, d0 = w.delta0, d1 = w.delta1, d2 = w.delta2;
+    int l0 = w.left0, l1 = w.left1, l2 = w.left2, c0 = w.cstep0, c1 = w.cstep1, c2 = w.cstep2;
+    asm("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(d0), "+v"(d1), "+v"(d2));
+    asm("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(c0), "+v"(c1), "+v"(c2));
+    const bool c01 = n0 < n1, c02 = n0 < n2, c12 = n1 < n2;
     const bool is0 = c01 && c02;
     const bool is1 = !c01 && c12;
-    const float nx_t = is0 ? w.next[0] : (is1 ? w.next[1] : w.next[2]);
+    const bool is2 = !(is0 || is1);
+    const float nx_t = is0 ? n0 : (is1 ? n1 : n2);
     if (early_hit) {
         const float lim = best_t + fabsf(best_t) * slack;
         if (lim < nx_t) return false;
     }
-    const int lf = is0 ? w.left[0] : (is1 ? w.left[1] : w.left[2]);
+    const int lf = is0 ? l0 : (is1 ? l1 : l2);
     if (lf == 0) return false;                      // Pos[stepAxis] == Out[stepAxis]
-    const float dl = is0 ? w.delta[0] : (is1 ? w.delta[1] : w.delta[2]);
-    const int cs = is0 ? w.cstep[0] : (is1 ? w.cstep[1] : w.cstep[2]);
+    const float dl = is0 ? d0 : (is1 ? d1 : d2);
+    const int cs = is0 ? c0 : (is1 ? c1 : c2);
     const float nn = nx_t + dl;
-    w.next[0] = is0 ? nn : w.next[0];
-    w.next[1] = is1 ? nn : w.next[1];
-    w.next[2] = (is0 || is1) ? w.next[2] : nn;
-    w.left[0] = is0 ? lf - 1 : w.left[0];
-    w.left[1] = is1 ? lf - 1 : w.left[1];
-    w.left[2] = (is0 || is1) ? w.left[2] : lf - 1;
+    w.next0 = is0 ? nn : n0;
+    w.next1 = is1 ? nn : n1;
+    w.next2 = is2 ? nn : n2;
+    w.left0 = is0 ? lf - 1 : l0;
+    w.left1 = is1 ? lf - 1 : l1;
+    w.left2 = is2 ? lf - 1 : l2;
     w.cell += cs;
     return true;
 }
@@ -695,23 +705,26 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 // The divisions are only executed when the signs allow beta > 0 and gamma > 0 and the numerators allow
 // beta + gamma < 1 with a 1e-12 relative margin; inside that margin the reference's own expression decides.
 template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT>
-__device__ __forceinline__ bool wave_walk(const GridU& g, const RtSceneDev& s, const uint32_t* bitmap, int lane, bool active, float ox,
+__device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* bitmap, int lane, bool active, float ox,
                                           float oy, float oz, float dx, float dy, float dz, float mint, bool use_eps, float eps,
-                                          bool early, float slack, Nearest& st, WalkCount& wc) {
+                                          bool early, float slack, uint32_t cull_min, Nearest& st, WalkCount& wc) {
     Dda w;
     bool alive = false;
-    if (active) {
+    if (__ballot(active)) {
+        const GridU g = load_grid(s.grid);          // only needed for the set-up of the walk
+        if (active) {
         float rayT;
         alive = grid_entry(g, ox, oy, oz, dx, dy, dz, mint, rayT);
         if (alive) {
             if (COUNT) { wc.entered = 1; wc.steps = 1; }
             dda_setup(w, g, ox, oy, oz, dx, dy, dz, rayT);
         }
+        }
     }
     bool hit = false;
     bool first = true;
     const double ddx = dx, ddy = dy, ddz = dz;
-    const double idx = 1.0 / ddx, idy = 1.0 / ddy, idz = 1.0 / ddz;     // for the per-run box test
+    const float ifx = (float)(1.0 / ddx), ify = (float)(1.0 / ddy), ifz = (float)(1.0 / ddz);     // for the per-run box test
     for (;;) {
         // ---- STEP: on to the next occupied voxel
         const long long t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -730,170 +743,208 @@ __device__ __forceinline__ bool wave_walk(const GridU& g, const RtSceneDev& s, c
         if (alive) { cbeg = s.cell_start[w.cell]; cend = s.cell_start[w.cell + 1]; }
         const long long t1 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (COUNT) { wc.rounds += 1; wc.cyc_step += (uint32_t)(t1 - t0); if (alive) wc.tests += cend - cbeg; }
-        // ---- TEST: one voxel after the other
-        while (un) {
-            const int leader = __ffsll((long long)un) - 1;
-            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)cbeg, leader);
-            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)cend, leader);
-            unsigned long long members = __ballot(alive && cbeg == b);
-            un &= ~members;
-            if (COUNT) wc.slots += 1;
-            // The voxel's records are visited in runs of 64 (lane = record). Crowded voxels use runs aligned to
-            // multiples of 64 in the record array, which is what the per-run boxes describe; small voxels start at
-            // their first record and usually fit one run.
-            const bool cull = (e - b) >= RT_CULL_MIN;
-            const uint32_t org = cull ? (b & ~63u) : b;
-            for (uint32_t r0 = org; r0 < e; r0 += 64u * 64u) {
-                const uint32_t runs_left = (e - r0 + 63u) >> 6;
-                const uint32_t n_run = runs_left < 64u ? runs_left : 64u;                     // runs in this pass
-                const uint32_t g0 = r0 >> 6;                                                  // first box (aligned case)
-                // ---- which runs does each ray need? Crowded voxels only: lane = run, its box against the ray's line.
-                unsigned long long need_any = (n_run == 64u) ? ~0ull : ((1ull << n_run) - 1ull);
-                unsigned long long my_need = need_any;           // lane i: runs ray i has to test
-                if (cull) {
-                    // lane = run: its box, grown by a margin far above the rounding of this test and of the reference's
-                    // double-precision triangle test, against the whole line of each ray (slab test); NaNs keep the run
-                    double blo[3] = {0, 0, 0}, bhi[3] = {0, 0, 0}, bm = 0;
-                    if ((uint32_t)lane < n_run) {
-                        const float4 q0 = s.blk_bounds[2ull * (g0 + lane)], q1 = s.blk_bounds[2ull * (g0 + lane) + 1];
-                        blo[0] = q0.x; blo[1] = q0.y; blo[2] = q0.z; bm = q0.w;
-                        bhi[0] = q1.x; bhi[1] = q1.y; bhi[2] = q1.z;
-                    }
-                    if (SHARED_ORIGIN) {      // box relative to the common origin, once per voxel
-                        const double mg = 1e-6 * (bm + fabs((double)ox) + fabs((double)oy) + fabs((double)oz)) + 1e-30;
-                        const double ro[3] = {(double)ox, (double)oy, (double)oz};
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) { blo[a] = (blo[a] - mg) - ro[a]; bhi[a] = (bhi[a] + mg) - ro[a]; }
-                    }
-                    need_any = 0;
-                    unsigned long long lm = members;
-                    while (lm) {
-                        const int i = __ffsll((long long)lm) - 1;
-                        lm &= lm - 1;
-                        const double ri[3] = {bcast_f64(idx, i), bcast_f64(idy, i), bcast_f64(idz, i)};
-                        double lo_[3] = {blo[0], blo[1], blo[2]}, hi_[3] = {bhi[0], bhi[1], bhi[2]};
-                        if (!SHARED_ORIGIN) {
-                            const double ro[3] = {(double)bcast_f32(ox, i), (double)bcast_f32(oy, i), (double)bcast_f32(oz, i)};
-                            const double mg = 1e-6 * (bm + fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2])) + 1e-30;
-#pragma unroll
-                            for (int a = 0; a < 3; ++a) { lo_[a] = (blo[a] - mg) - ro[a]; hi_[a] = (bhi[a] + mg) - ro[a]; }
-                        }
-                        double t0 = -INFINITY, t1 = INFINITY;
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            const double ta = lo_[a] * ri[a], tb = hi_[a] * ri[a];
-                            t0 = fmax(t0, fmin(ta, tb));
-                            t1 = fmin(t1, fmax(ta, tb));
-                        }
-                        const unsigned long long m = __ballot((uint32_t)lane < n_run && !(t0 > t1));
-                        need_any |= m;
-                        if (lane == i) my_need = m;
-                    }
+        // ---- CULL (crowded voxels only): every ray against the boxes of the 64-record runs of ITS voxel, lane = ray.
+        // A voxel's records are visited in runs of 64. Crowded voxels use runs aligned to multiples of 64 in the record
+        // array, which is what the per-run boxes describe; a run is skipped for a ray when the ray's whole line misses
+        // the run's box grown by a margin far above the rounding of this test and of the reference's double-precision
+        // triangle test (NaNs keep the run). Small voxels start at their first record and usually fit one run.
+        // need[k>>6] bit (k&63) = this ray has to test run k of its voxel; runs from 128 on are always tested.
+        const bool cull = alive && (cend - cbeg) >= cull_min;
+        const uint32_t org = cull ? (cbeg & ~63u) : cbeg;
+        const uint32_t nrun_me = (cend - org + 63u) >> 6;
+        unsigned long long need0 = ~0ull, need1 = ~0ull;
+        // FP32 slab test of a ray's whole line against a run's box. Every slab is widened by
+        // mg = 4e-6 * (largest |coordinate| of the box + |origin|), more than 20 times the rounding error of the
+        // expressions below, so a line that touches the true box is always kept; fminf/fmaxf drop NaNs (0 * inf),
+        // which keeps the run as well.
+        auto box_hit = [](const float4 q0, const float4 q1, float rox, float roy, float roz, float rix, float riy, float riz) -> bool {
+            const float mg = 4e-6f * (q0.w + (fabsf(rox) + fabsf(roy) + fabsf(roz))) + 1e-30f;
+            const float ax0 = ((q0.x - mg) - rox) * rix, ax1 = ((q1.x + mg) - rox) * rix;
+            const float ay0 = ((q0.y - mg) - roy) * riy, ay1 = ((q1.y + mg) - roy) * riy;
+            const float az0 = ((q0.z - mg) - roz) * riz, az1 = ((q1.z + mg) - roz) * riz;
+            const float t0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+            const float t1 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+            return !(t0 > t1);
+        };
+        // (a) voxels with up to RT_CULL_LANE_RUNS runs: lane = ray, a short loop over the runs of its own voxel,
+        //     all voxels of the round at once
+        if (cull && nrun_me <= RT_CULL_LANE_RUNS) {
+            const float4* bb = s.blk_bounds + 2ull * (org >> 6);
+            need0 = 0;
+#pragma unroll 4
+            for (uint32_t k = 0; k < nrun_me; ++k)
+                if (box_hit(bb[2 * k], bb[2 * k + 1], ox, oy, oz, ifx, ify, ifz)) need0 |= 1ull << k;
+        }
+        // (b) more crowded voxels, one after the other: lane = run (up to 128 of them), the rays standing in the voxel
+        //     are broadcast one by one; runs from 128 on are always tested
+        {
+            unsigned long long dn = __ballot(cull && nrun_me > RT_CULL_LANE_RUNS);
+            while (dn) {
+                const int leader = __ffsll((long long)dn) - 1;
+                const uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)cbeg, leader);
+                const uint32_t vn = (uint32_t)__builtin_amdgcn_readlane((int)nrun_me, leader);
+                const uint32_t vo = (uint32_t)__builtin_amdgcn_readlane((int)org, leader) >> 6;
+                const unsigned long long mem = __ballot(cull && cbeg == vb);
+                dn &= ~mem;
+                float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+                const bool h0 = (uint32_t)lane < vn, h1 = (uint32_t)lane + 64u < vn;
+                if (h0) { a0 = s.blk_bounds[2ull * (vo + lane)]; a1 = s.blk_bounds[2ull * (vo + lane) + 1]; }
+                if (h1) { b0 = s.blk_bounds[2ull * (vo + 64u + lane)]; b1 = s.blk_bounds[2ull * (vo + 64u + lane) + 1]; }
+                unsigned long long lm = mem;
+                while (lm) {
+                    const int i = __ffsll((long long)lm) - 1;
+                    lm &= lm - 1;
+                    const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
+                    const float rix = bcast_f32(ifx, i), riy = bcast_f32(ify, i), riz = bcast_f32(ifz, i);
+                    const unsigned long long m0 = __ballot(h0 && box_hit(a0, a1, rox, roy, roz, rix, riy, riz));
+                    const unsigned long long m1 = (vn > 64u) ? __ballot(h1 && box_hit(b0, b1, rox, roy, roz, rix, riy, riz)) : 0ull;
+                    if (lane == i) { need0 = m0; need1 = m1; }
                 }
-                // ---- the needed runs, in ascending order; the next needed run is prefetched during the tests
-                float4 n0, n1, n2;
-                if (need_any) {
-                    const uint32_t p = r0 + ((uint32_t)__ffsll((long long)need_any) - 1u) * 64u + lane;
-                    const float4* r = s.recs + 3ull * ((p >= b && p < e) ? p : b);
-                    n0 = r[0]; n1 = r[1]; n2 = r[2];
+            }
+        }
+        // ---- TEST: the round's (voxel, needed run) items in order: voxels by their lowest lane, runs ascending. The
+        // generator runs one item ahead of the tests so that the next run's records are in flight, also across voxels.
+        uint32_t sb = 0, se = 0, sorg = 0, sk = 0, snrun = 0;
+        unsigned long long smem = 0;
+        bool scull = false;
+        struct Item { uint32_t base, b, e; unsigned long long rays; };
+        auto next_item = [&](Item& it) -> bool {
+            for (;;) {
+                if (sk >= snrun) {
+                    if (!un) return false;
+                    const int leader = __ffsll((long long)un) - 1;
+                    sb = (uint32_t)__builtin_amdgcn_readlane((int)cbeg, leader);
+                    se = (uint32_t)__builtin_amdgcn_readlane((int)cend, leader);
+                    smem = __ballot(alive && cbeg == sb);
+                    un &= ~smem;
+                    scull = (se - sb) >= cull_min;
+                    sorg = scull ? (sb & ~63u) : sb;
+                    snrun = (se - sorg + 63u) >> 6;
+                    sk = 0;
+                    if (COUNT) wc.slots += 1;
                 }
-                while (need_any) {
-                    const int k = __ffsll((long long)need_any) - 1;
-                    need_any &= need_any - 1;
-                    const uint32_t base = r0 + (uint32_t)k * 64u;
-                    const bool have = base + lane >= b && base + lane < e;
-                    const TriRec t = unpack_rec(n0, n1, n2);
-                    if (COUNT) wc.lanes += (uint32_t)__popcll(__ballot(have)) * (uint32_t)__popcll(members & __ballot((my_need >> k) & 1ull));
-                    if (need_any) {
-                        const uint32_t p = r0 + ((uint32_t)__ffsll((long long)need_any) - 1u) * 64u + lane;
-                        const float4* r = s.recs + 3ull * ((p >= b && p < e) ? p : b);
-                        n0 = r[0]; n1 = r[1]; n2 = r[2];
-                    }
-                    // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
-                    double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
-                    if (SHARED_ORIGIN) {
-                        sx = t.v0x - ox; sy = t.v0y - oy; sz = t.v0z - oz;        // float subtractions, then widened
+                const uint32_t k = sk++;
+                unsigned long long rays = smem & __ballot(alive);       // shadow query: rays already hit need no more runs
+                if (scull && k < 128u) rays &= __ballot((((k < 64u) ? need0 : need1) >> (k & 63u)) & 1ull);
+                if (rays) { it.base = sorg + 64u * k; it.b = sb; it.e = se; it.rays = rays; return true; }
+            }
+        };
+        auto load_item = [&](const Item& it, float4& r0, float4& r1, float4& r2) {
+            const uint32_t p = it.base + lane;
+            const float4* r = s.recs + 3ull * ((p >= it.b && p < it.e) ? p : it.b);
+            r0 = r[0]; r1 = r[1]; r2 = r[2];
+        };
+        Item cur, nxt;
+        float4 n0, n1, n2;
+        bool more = next_item(cur);
+        if (more) load_item(cur, n0, n1, n2);
+        while (more) {
+            const TriRec t = unpack_rec(n0, n1, n2);
+            const bool more_next = next_item(nxt);
+            if (more_next) load_item(nxt, n0, n1, n2);
+            const uint32_t base = cur.base, e = cur.e;
+            const bool have = base + lane >= cur.b && base + lane < e;
+            unsigned long long lm = cur.rays & __ballot(alive);          // rays that were hit meanwhile (shadow query) drop out
+            if (COUNT) wc.lanes += (uint32_t)__popcll(__ballot(have)) * (uint32_t)__popcll(lm);
+            if (lm) {
+                // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
+                double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
+                if (SHARED_ORIGIN) {
+                    sx = t.v0x - ox; sy = t.v0y - oy; sz = t.v0z - oz;        // float subtractions, then widened
+                    p_e2s = t.e2y * sz - sy * t.e2z;
+                    p_e1s = t.e1y * sz - sy * t.e1z;
+                }
+                while (lm) {
+                    const int i = __ffsll((long long)lm) - 1;
+                    lm &= lm - 1;
+                    const double rdx = bcast_f64(ddx, i), rdy = bcast_f64(ddy, i), rdz = bcast_f64(ddz, i);
+                    if (!SHARED_ORIGIN) {
+                        const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
+                        sx = t.v0x - rox; sy = t.v0y - roy; sz = t.v0z - roz;
                         p_e2s = t.e2y * sz - sy * t.e2z;
                         p_e1s = t.e1y * sz - sy * t.e1z;
                     }
-                    unsigned long long lm = members & __ballot((my_need >> k) & 1ull);
-                    while (lm) {
-                        const int i = __ffsll((long long)lm) - 1;
-                        lm &= lm - 1;
-                        const double rdx = bcast_f64(ddx, i), rdy = bcast_f64(ddy, i), rdz = bcast_f64(ddz, i);
-                        if (!SHARED_ORIGIN) {
-                            const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
-                            sx = t.v0x - rox; sy = t.v0y - roy; sz = t.v0z - roz;
-                            p_e2s = t.e2y * sz - sy * t.e2z;
-                            p_e1s = t.e1y * sz - sy * t.e1z;
-                        }
-                        const double p_e2d = t.e2y * rdz - rdy * t.e2z;
-                        const double p_e1d = t.e1y * rdz - rdy * t.e1z;
-                        const double p_sd = sy * rdz - rdy * sz;
-                        const double A = t.e1x * p_e2d - t.e2x * p_e1d + rdx * t.m12;
-                        const double bnum = sx * p_e2d - t.e2x * p_sd - rdx * p_e2s;
-                        const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
-                        const bool pos = (A > 0.0) && (bnum > 0.0) && (gnum > 0.0);
-                        const bool neg = (A < 0.0) && (bnum < 0.0) && (gnum < 0.0);
-                        bool pass = false;
-                        double tt = 0.0;
-                        if (have && (pos || neg) && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12))) {
-                            const double beta = bnum / A;
-                            const double gamma = gnum / A;
-                            if (beta > 0 && gamma > 0 && beta + gamma < 1) {
-                                pass = true;
-                                if (!ANY_HIT) {
-                                    const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
-                                    tt = tnum / A;
-                                }
+                    const double p_e2d = t.e2y * rdz - rdy * t.e2z;
+                    const double p_e1d = t.e1y * rdz - rdy * t.e1z;
+                    const double p_sd = sy * rdz - rdy * sz;
+                    const double A = t.e1x * p_e2d - t.e2x * p_e1d + rdx * t.m12;
+                    const double bnum = sx * p_e2d - t.e2x * p_sd - rdx * p_e2s;
+                    const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
+                    const bool pos = (A > 0.0) && (bnum > 0.0) && (gnum > 0.0);
+                    const bool neg = (A < 0.0) && (bnum < 0.0) && (gnum < 0.0);
+                    bool pass = false;
+                    double tt = 0.0;
+                    if (have && (pos || neg) && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12))) {
+                        const double beta = bnum / A;
+                        const double gamma = gnum / A;
+                        if (beta > 0 && gamma > 0 && beta + gamma < 1) {
+                            pass = true;
+                            if (!ANY_HIT) {
+                                const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
+                                tt = tnum / A;
                             }
                         }
-                        unsigned long long pm = __ballot(pass);
-                        if (pm) {
-                            if (ANY_HIT) {
-                                members &= ~(1ull << i);
+                    }
+                    unsigned long long pm = __ballot(pass);
+                    if (pm) {
+                        if (ANY_HIT) {
+                            if (lane == i) {
+                                hit = true; alive = false;
+                                if (COUNT) wc.tests -= e - (base + (uint32_t)__ffsll((long long)pm));   // tests the reference order skips
+                            }
+                        } else {
+                            if (lane == i) hit = true;
+                            // apply the passing triangles in ascending lane order = ascending triangle order
+                            while (pm) {
+                                const int pl = __ffsll((long long)pm) - 1;
+                                pm &= pm - 1;
+                                const double t_p = bcast_f64(tt, pl);
+                                const int id_p = __builtin_amdgcn_readlane((int)t.id, pl);
                                 if (lane == i) {
-                                    hit = true; alive = false;
-                                    if (COUNT) wc.tests -= e - (base + (uint32_t)__ffsll((long long)pm));   // tests the reference order skips
-                                }
-                            } else {
-                                if (lane == i) hit = true;
-                                // apply the passing triangles in ascending lane order = ascending triangle order
-                                while (pm) {
-                                    const int pl = __ffsll((long long)pm) - 1;
-                                    pm &= pm - 1;
-                                    const double t_p = bcast_f64(tt, pl);
-                                    const int id_p = __builtin_amdgcn_readlane((int)t.id, pl);
-                                    if (lane == i) {
-                                        if (t_p < (double)st.t) {
-                                            if (!use_eps || t_p > (double)eps) { st.t = (float)t_p; st.id = id_p; }
-                                        }
+                                    if (t_p < (double)st.t) {
+                                        if (!use_eps || t_p > (double)eps) { st.t = (float)t_p; st.id = id_p; }
                                     }
                                 }
                             }
                         }
                     }
-                    if (ANY_HIT && !members) break;
                 }
-                if (ANY_HIT && !members) break;
             }
+            cur = nxt;
+            more = more_next;
         }
         if (COUNT) wc.cyc_test += (uint32_t)((long long)__builtin_amdgcn_s_memtime() - t1);
     }
     return hit;
 }
 
+struct RtTraceArgs {
+    RtSceneDev s;
+    RtCamera cam;
+    RtShade sh;
+    RtFrame f;
+    RtOutputs o;
+    uint32_t* work;
+    const uint32_t* tile_list;
+};
+
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o,
-                                                                    uint32_t* work, const uint32_t* __restrict__ tile_list) {
+__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArgs args_in_kernarg_segment) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
+    // The ~80 dwords of frame constants are read from the kernel-argument segment where they are needed (scalar
+    // loads, cached) instead of living in scalar registers for the whole persistent loop, where they would be
+    // spilled; the empty asm at the top of the loop keeps the compiler from hoisting those loads back out.
+    (void)args_in_kernarg_segment;
+    const RtTraceArgs* A = reinterpret_cast<const RtTraceArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+    uint32_t* const work = A->work;
+    const uint32_t* const tile_list = A->tile_list;
 
     const uint32_t n_listed = work[0];
     if (n_listed == 0) return;
-    const GridU g = load_grid(s.grid);
     {
+        const RtSceneDev& s = A->s;
         // occupancy bitmap of the whole grid into LDS, once per block
         const int words = (s.grid->n_cells + 31) >> 5;
         for (int i = threadIdx.x; i < words; i += blockDim.x) bitmap[i] = s.occupancy[i];
@@ -903,11 +954,18 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s,
     // Work unit of a wavefront: a whole 8x8 tile (64 rays), or half (8x4) or a quarter (4x4) of one when the
     // frame lists few tiles per wavefront, so that the longest-running tile does not set the frame time.
     const uint32_t n_waves = gridDim.x * RT_WAVES_PER_BLOCK;
-    const int ushift = f.unit_shift >= 0 ? f.unit_shift : ((n_listed >= 24u * n_waves) ? 0 : ((n_listed >= 12u * n_waves) ? 1 : 2));
+    const int unit_shift = A->f.unit_shift;
+    const int ushift = unit_shift >= 0 ? unit_shift : ((n_listed >= 24u * n_waves) ? 0 : ((n_listed >= 12u * n_waves) ? 1 : 2));
     const uint32_t n_units = n_listed << ushift;
-    const uint32_t batch = (uint32_t)f.dequeue_batch;
+    const uint32_t batch = (uint32_t)A->f.dequeue_batch;
     uint32_t slot = 0, slot_end = 0;
     for (;; ++slot) {
+        asm volatile("" ::: "memory");
+        const RtSceneDev& s = A->s;
+        const RtCamera& cam = A->cam;
+        const RtShade& sh = A->sh;
+        const RtFrame& f = A->f;
+        const RtOutputs& o = A->o;
         if (slot >= slot_end) {         // take the next `batch` units with one atomic
             if (lane == 0) slot = atomicAdd(&work[1], batch);
             slot = __builtin_amdgcn_readfirstlane(slot);
@@ -935,8 +993,8 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s,
         Nearest st = {INFINITY, -1};
         WalkCount wp = {0, 0, 0, 0, 0, 0, 0, 0}, ws = {0, 0, 0, 0, 0, 0, 0, 0};
         const long long t_start = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        const bool hit = wave_walk<false, true, COUNT>(g, s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
-                                                       sh.eps, f.walk_full == 0, f.early_slack, st, wp);
+        const bool hit = wave_walk<false, true, COUNT>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
+                                                       sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, st, wp);
         float cr = 0.f, cg = 0.f, cb = 0.f;
         float colr = 0.f, colg = 0.f, colb = 0.f;
         float poix = 0.f, poiy = 0.f, poiz = 0.f, sx = 0.f, sy = 0.f, sz = 1.f;
@@ -974,8 +1032,8 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s,
             sx = -(sh.light[0] - poix); sy = -(sh.light[1] - poiy); sz = -(sh.light[2] - poiz);
             normalize3(sx, sy, sz);
         }
-        const bool shadowed = wave_walk<true, false, COUNT>(g, s, bitmap, lane, hit, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
-                                                            true, 0.f, st, ws);
+        const bool shadowed = wave_walk<true, false, COUNT>(s, bitmap, lane, hit, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
+                                                            true, 0.f, (uint32_t)f.cull_min, st, ws);
         if (hit) {
             if (shadowed) { cr = cr * sh.shadow_scale; cg = cg * sh.shadow_scale; cb = cb * sh.shadow_scale; }
             cr = cr + colr * sh.ka; cg = cg + colg * sh.ka; cb = cb + colb * sh.ka;
@@ -1006,6 +1064,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64) k_trace(RtSceneDev s,
                     atomicAdd(&o.counters[13], 1ull);
                     atomicMax(&o.counters[14], (unsigned long long)(wp.rounds + ws.rounds));
                     atomicAdd(&o.counters[16], (unsigned long long)wp.lanes + (unsigned long long)ws.lanes);
+                    if (o.unit_cost) o.unit_cost[slot] = (uint32_t)cyc;
                 }
             }
         }
@@ -1024,8 +1083,10 @@ hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, R
     int blocks = wk.n_cu * wk.blocks_per_cu;
     const int max_useful = (tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK;
     if (blocks > max_useful) blocks = max_useful;
-    if (f.count_work) k_trace<true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(s, cam, sh, f, o, wk.work, wk.tile_list);
-    else k_trace<false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(s, cam, sh, f, o, wk.work, wk.tile_list);
+    RtTraceArgs ta;
+    ta.s = s; ta.cam = cam; ta.sh = sh; ta.f = f; ta.o = o; ta.work = wk.work; ta.tile_list = wk.tile_list;
+    if (f.count_work) k_trace<true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+    else k_trace<false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     return hipGetLastError();
 }
 

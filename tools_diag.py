@@ -15,3 +15,13 @@ for w in sys.argv[1:]:
           "max rounds", st["tile_rounds_max"], "streams/round", round(st["sched_streams"] / r, 2), "cyc step/tile", int(st["sched_lanes"] / t), "cyc test/tile", int(st["cycles_test"] / t),
           "tile cycles avg", int(st["tile_cycles_sum"] / t), "max", st["tile_cycles_max"],
           "tests", st["tests_primary"] + st["tests_shadow"], "executed", st["tests_executed"], "steps", st["steps_primary"] + st["steps_shadow"])
+    import numpy as np
+    c = scene.unit_costs(((W + 7) // 8) * ((H + 7) // 8) * 64)
+    c = c[c > 0].astype(np.float64)
+    if len(c):
+        c.sort()
+        tot = c.sum()
+        print("   units", len(c), "cycles: mean %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f | share of total in top 1%% units: %.2f, top 0.1%%: %.2f" % (
+            c.mean(), c[len(c)//2], c[int(len(c)*0.9)], c[int(len(c)*0.99)], c[int(len(c)*0.999)], c[-1], c[int(len(c)*0.99):].sum()/tot, c[int(len(c)*0.999):].sum()/tot))
+        nw = 4096
+        print("   ideal balanced = total/%d waves = %.0f cycles ; max unit = %.0f" % (nw, tot / nw, c[-1]))
