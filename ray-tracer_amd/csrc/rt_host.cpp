@@ -471,7 +471,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.early_slack = 0.f;
     f.count_work = s->count_work ? 1 : 0;
     { const char* e = getenv("RT_UNIT_SHIFT"); f.unit_shift = e ? atoi(e) : -1; }
-    { const char* e = getenv("RT_CULL_MIN"); f.cull_min = e ? atoi(e) : 96; }
+    { const char* e = getenv("RT_CULL_MIN"); const char* e2 = getenv("RT_CULL_LANE_RUNS"); f.cull_min = (e ? atoi(e) : 96) | ((e2 ? atoi(e2) : 12) << 16); }
     { const char* e = getenv("RT_DEQUEUE_BATCH"); f.dequeue_batch = e ? atoi(e) : 1; if (f.dequeue_batch < 1) f.dequeue_batch = 1; }
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;

@@ -650,6 +650,11 @@ __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t
 __device__ __forceinline__ float bcast_f32(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
+__device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, int src_lane) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)v, src_lane);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ double bcast_f64(double v, int src_lane) {
     const long long b = __double_as_longlong(v);
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, src_lane);
@@ -749,10 +754,10 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // the run's box grown by a margin far above the rounding of this test and of the reference's double-precision
         // triangle test (NaNs keep the run). Small voxels start at their first record and usually fit one run.
         // need[k>>6] bit (k&63) = this ray has to test run k of its voxel; runs from 128 on are always tested.
-        const bool cull = alive && (cend - cbeg) >= cull_min;
+        const bool cull = alive && (cend - cbeg) >= (cull_min & 0xffffu);
         const uint32_t org = cull ? (cbeg & ~63u) : cbeg;
         const uint32_t nrun_me = (cend - org + 63u) >> 6;
-        unsigned long long need0 = ~0ull, need1 = ~0ull;
+        unsigned long long need0 = ~0ull, need1 = ~0ull, any0 = ~0ull, any1 = ~0ull;
         // FP32 slab test of a ray's whole line against a run's box. Every slab is widened by
         // mg = 4e-6 * (largest |coordinate| of the box + |origin|), more than 20 times the rounding error of the
         // expressions below, so a line that touches the true box is always kept; fminf/fmaxf drop NaNs (0 * inf),
@@ -768,7 +773,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         };
         // (a) voxels with up to RT_CULL_LANE_RUNS runs: lane = ray, a short loop over the runs of its own voxel,
         //     all voxels of the round at once
-        if (cull && nrun_me <= RT_CULL_LANE_RUNS) {
+        if (cull && nrun_me <= (cull_min >> 16)) {
             const float4* bb = s.blk_bounds + 2ull * (org >> 6);
             need0 = 0;
 #pragma unroll 4
@@ -778,7 +783,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // (b) more crowded voxels, one after the other: lane = run (up to 128 of them), the rays standing in the voxel
         //     are broadcast one by one; runs from 128 on are always tested
         {
-            unsigned long long dn = __ballot(cull && nrun_me > RT_CULL_LANE_RUNS);
+            unsigned long long dn = __ballot(cull && nrun_me > (cull_min >> 16));
             while (dn) {
                 const int leader = __ffsll((long long)dn) - 1;
                 const uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)cbeg, leader);
@@ -790,7 +795,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 const bool h0 = (uint32_t)lane < vn, h1 = (uint32_t)lane + 64u < vn;
                 if (h0) { a0 = s.blk_bounds[2ull * (vo + lane)]; a1 = s.blk_bounds[2ull * (vo + lane) + 1]; }
                 if (h1) { b0 = s.blk_bounds[2ull * (vo + 64u + lane)]; b1 = s.blk_bounds[2ull * (vo + 64u + lane) + 1]; }
-                unsigned long long lm = mem;
+                unsigned long long lm = mem, u0 = 0, u1 = 0;
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
                     lm &= lm - 1;
@@ -799,13 +804,15 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     const unsigned long long m0 = __ballot(h0 && box_hit(a0, a1, rox, roy, roz, rix, riy, riz));
                     const unsigned long long m1 = (vn > 64u) ? __ballot(h1 && box_hit(b0, b1, rox, roy, roz, rix, riy, riz)) : 0ull;
                     if (lane == i) { need0 = m0; need1 = m1; }
+                    u0 |= m0; u1 |= m1;
                 }
+                if (lane == leader) { any0 = u0; any1 = u1; }      // runs some ray of this voxel needs, kept in its first lane
             }
         }
         // ---- TEST: the round's (voxel, needed run) items in order: voxels by their lowest lane, runs ascending. The
         // generator runs one item ahead of the tests so that the next run's records are in flight, also across voxels.
         uint32_t sb = 0, se = 0, sorg = 0, sk = 0, snrun = 0;
-        unsigned long long smem = 0;
+        unsigned long long smem = 0, sany0 = ~0ull, sany1 = ~0ull;
         bool scull = false;
         struct Item { uint32_t base, b, e; unsigned long long rays; };
         auto next_item = [&](Item& it) -> bool {
@@ -817,12 +824,24 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     se = (uint32_t)__builtin_amdgcn_readlane((int)cend, leader);
                     smem = __ballot(alive && cbeg == sb);
                     un &= ~smem;
-                    scull = (se - sb) >= cull_min;
+                    scull = (se - sb) >= (cull_min & 0xffffu);
                     sorg = scull ? (sb & ~63u) : sb;
                     snrun = (se - sorg + 63u) >> 6;
                     sk = 0;
+                    sany0 = ~0ull; sany1 = ~0ull;
+                    if (scull && snrun > (cull_min >> 16)) { sany0 = bcast_u64(any0, leader); sany1 = bcast_u64(any1, leader); }
                     if (COUNT) wc.slots += 1;
                 }
+                // crowded voxels: straight to the next run that some ray needs
+                if (sk < 64u) {
+                    const unsigned long long rest = sany0 & (~0ull << sk);
+                    sk = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u;
+                }
+                if (sk >= 64u && sk < 128u) {
+                    const unsigned long long rest = sany1 & (~0ull << (sk - 64u));
+                    sk = rest ? 64u + (uint32_t)__ffsll((long long)rest) - 1u : 128u;
+                }
+                if (sk >= snrun) continue;
                 const uint32_t k = sk++;
                 unsigned long long rays = smem & __ballot(alive);       // shadow query: rays already hit need no more runs
                 if (scull && k < 128u) rays &= __ballot((((k < 64u) ? need0 : need1) >> (k & 63u)) & 1ull);
