@@ -77,7 +77,10 @@ typedef struct rt_frame_stats {
      * served over all rounds, shader-clock cycles per traced tile (max, sum), traced tiles, most rounds in one tile */
     uint64_t sched_rounds, sched_streams, sched_lanes /* cycles in the step phase */, tile_cycles_max, tile_cycles_sum, tiles_traced, tile_rounds_max,
         cycles_test /* cycles in the test phase */,
-        tests_executed /* triangle tests actually run: runs whose box the ray's line misses are skipped */;
+        tests_executed /* triangle tests actually run: runs whose box the ray's line misses are skipped */,
+        runs_streamed /* 64-record runs read by wavefronts */,
+        run_ray_trips /* (run, ray) iterations of the test loop */,
+        cycles_cull /* cycles in the run culling */;
 } rt_frame_stats;
 
 const char* rt_last_error(void);

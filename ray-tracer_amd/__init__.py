@@ -46,6 +46,7 @@ class FrameStats(C.Structure):
         ("sched_rounds", C.c_uint64), ("sched_streams", C.c_uint64), ("sched_lanes", C.c_uint64),
         ("tile_cycles_max", C.c_uint64), ("tile_cycles_sum", C.c_uint64), ("tiles_traced", C.c_uint64),
         ("tile_rounds_max", C.c_uint64), ("cycles_test", C.c_uint64), ("tests_executed", C.c_uint64),
+        ("runs_streamed", C.c_uint64), ("run_ray_trips", C.c_uint64), ("cycles_cull", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -40,8 +40,7 @@ struct RtFrame {
     int32_t walk_full;            // 1 = walk every primary ray to the grid exit
     float early_slack;
     int32_t count_work;           // 1 = the kernel also counts voxel steps and triangle tests
-    int32_t unit_shift;           // -1 = choose per frame; 0/1/2 = whole, half or quarter tiles per wavefront
-    int32_t dequeue_batch;        // work units a wavefront takes from the queue per atomic
+    int32_t unit_shifts;          // 4 bits per cost class (class 0 in bits 8..11): log2 of the units a tile is cut into
     int32_t cull_min;             // voxels with at least this many triangles get the per-run box test
 };
 
@@ -69,8 +68,12 @@ struct RtOutputs {
 
 // Per-frame work list of the render kernels.
 struct RtRenderWork {
-    uint32_t* work;               // [0] listed tiles, [1] dequeue head; zeroed before each frame
+    uint32_t* work;               // [0] listed tiles, [1] dequeue head, [2..4] tiles per cost class; zeroed before each frame
     uint32_t* tile_list;          // capacity = tiles of the frame
+    uint32_t* cost;               // estimated cost per listed tile
+    unsigned long long* cost_sum; // zeroed before each frame
+    uint32_t* list[3];            // tiles per cost class (0 = most expensive), capacity = tiles of the frame each
+    float thr0, thr1;             // class limits: 1/thr0 and 1/thr1 of a wavefront's even share of the frame's estimate
     int32_t bitmap_words;         // LDS words reserved for the occupancy bitmap (>= ceil(n_cells / 32))
     int32_t n_cu, blocks_per_cu;
     int32_t tx0, ntx, tb0, ntb;   // tile columns x local bands that may see the grid (conservative); the rest stays background

@@ -70,7 +70,7 @@ struct rt_scene {
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
     DevBuf<float4> recs, blk_bounds;
     DevBuf<unsigned long long> counters;   // 20 frame counters + one 8-byte slot holding the two work-list words
-    DevBuf<uint32_t> tile_list, unit_cost;
+    DevBuf<uint32_t> tile_list, unit_cost, tile_cost, cls_list[3];
     int n_cu = 0;
     uint32_t known_cells = 0;              // n_cells of the current triangle list once measured
     RtGrid h_grid;                         // grid description of the current triangle list once measured
@@ -82,6 +82,10 @@ struct rt_scene {
     bool built[RT_STATS_RING] = {};
     uint64_t frames = 0;               // frames rendered so far; frame k uses ring slot k % RT_STATS_RING
     bool count_work = false;
+    // scheduling of the trace kernel: a tile is in cost class 0 (1) when its estimate exceeds 1/thr0 (1/thr1) of the even
+    // share of one wavefront; log2 of the work units a tile of each class is cut into, and the queue order of the classes
+    float sched_thr0 = 1.5f, sched_thr1 = 8.f;
+    int sched_shifts = (2 << 8) | (2 << 4) | 0 | (0 << 12) | (2 << 14) | (1 << 16);   // shifts of class 0,1,2; queue order in bits 12..17
     hipStream_t last_stream = nullptr;
     rt_params last_params;
 };
@@ -89,6 +93,18 @@ struct rt_scene {
 extern "C" rt_scene* rt_scene_create(void) {
     rt_scene* s = new (std::nothrow) rt_scene();
     if (s) memset(&s->last_params, 0, sizeof(s->last_params));
+    if (s) {
+        // experiment override: RT_SCHED="thr0:thr1:shift0:shift1:shift2[:order]", order = the three class digits in queue order
+        const char* e = getenv("RT_SCHED");
+        float a, b; int u0, u1, u2, ord = 12;
+        if (e && sscanf(e, "%f:%f:%d:%d:%d:%d", &a, &b, &u0, &u1, &u2, &ord) >= 5 && u0 >= 0 && u0 <= 6 && u1 >= 0 && u1 <= 6 && u2 >= 0 && u2 <= 6) {
+            const int o0 = (ord / 100) % 10, o1 = (ord / 10) % 10, o2 = ord % 10;
+            if (o0 < 3 && o1 < 3 && o2 < 3 && o0 != o1 && o0 != o2 && o1 != o2) {
+                s->sched_thr0 = a; s->sched_thr1 = b;
+                s->sched_shifts = (u0 << 8) | (u1 << 4) | u2 | (o0 << 12) | (o1 << 14) | (o2 << 16);
+            }
+        }
+    }
     return s;
 }
 
@@ -98,7 +114,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         (void)hipSetDevice(s->device);
         s->v0.release(); s->v1.release(); s->v2.release(); s->d_mesh_color.release(); s->d_grid.release();
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
-        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release();
+        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); for (auto& l : s->cls_list) l.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
         for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
     }
@@ -308,7 +324,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
-        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(21)))
+        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(32)))
         return rc;
     HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
     HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
@@ -452,7 +468,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         s->built[slot] = true;
     }
     HIP_TRY(hipEventRecord(s->ev[slot][1], st));
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 21 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 32 * sizeof(unsigned long long), st));
 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
@@ -470,9 +486,8 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.walk_full = (p->walk_mode == RT_WALK_FULL);
     f.early_slack = 0.f;
     f.count_work = s->count_work ? 1 : 0;
-    { const char* e = getenv("RT_UNIT_SHIFT"); f.unit_shift = e ? atoi(e) : -1; }
+    f.unit_shifts = s->sched_shifts;
     { const char* e = getenv("RT_CULL_MIN"); const char* e2 = getenv("RT_CULL_LANE_RUNS"); f.cull_min = (e ? atoi(e) : 96) | ((e2 ? atoi(e2) : 12) << 16); }
-    { const char* e = getenv("RT_DEQUEUE_BATCH"); f.dequeue_batch = e ? atoi(e) : 1; if (f.dequeue_batch < 1) f.dequeue_batch = 1; }
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;
@@ -503,7 +518,12 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
             HIP_TRY(hipMemsetAsync(s->unit_cost.p, 0, (tiles ? tiles : 1) * 64 * sizeof(uint32_t), st));
             o.unit_cost = s->unit_cost.p;
         }
-        wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 20);
+        wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 24);
+        wk.cost_sum = s->counters.p + 20;
+        if ((rc = s->tile_cost.ensure(tiles ? tiles : 1))) return rc;
+        wk.cost = s->tile_cost.p;
+        for (int k = 0; k < 3; ++k) { if ((rc = s->cls_list[k].ensure(tiles ? tiles : 1))) return rc; wk.list[k] = s->cls_list[k].p; }
+        wk.thr0 = s->sched_thr0; wk.thr1 = s->sched_thr1;
         wk.tile_list = s->tile_list.p;
         // LDS for the occupancy bitmap: exact once the grid of this triangle list has been measured
         const uint32_t cells = s->refs_known ? s->known_cells : (uint32_t)RT_MAX_CELLS;
@@ -597,6 +617,7 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     out->shadow_entering = c[5]; out->steps_shadow = c[6]; out->tests_shadow = c[7];
     out->sched_rounds = c[8]; out->sched_streams = c[9]; out->sched_lanes = c[10];
     out->tile_cycles_max = c[11]; out->tile_cycles_sum = c[12]; out->tiles_traced = c[13]; out->tile_rounds_max = c[14]; out->cycles_test = c[15]; out->tests_executed = c[16];
+    out->runs_streamed = c[17]; out->run_ray_trips = c[18]; out->cycles_cull = c[19];
     return RT_OK;
 }
 

@@ -466,6 +466,7 @@ struct WalkCount {           // work counters of one ray (only maintained by the
     uint32_t entered, steps, tests;
     uint32_t rounds, slots, lanes;   // per wavefront (identical in every lane): scheduling rounds, voxel visits, triangle tests executed
     uint32_t cyc_step, cyc_test;     // shader cycles spent in the two phases
+    uint32_t items, trips, cyc_cull; // record runs streamed, (run, ray) test iterations, cycles of the run culling
 };
 
 // Primary ray of pixel (x, y), Serial/raytracer.cpp:153-161; xw and yw are evaluated in double.
@@ -647,6 +648,102 @@ __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t
     return true;
 }
 
+// COST ESTIMATE per listed tile: the ray of the tile's centre pixel is walked through the whole grid (no triangle
+// tests) and the triangle counts of the occupied voxels it visits are summed. Tiles whose rays graze the surface or
+// cross crowded voxels get a large estimate; they are queued first and cut into smaller work units (k_bucket), so the
+// longest-running units start early and the frame does not end on a single wavefront.
+// work[] words: [0] listed tiles, [1] dequeue head, [2..4] tiles per cost class (0 = most expensive).
+#define RT_EST_CELLS 28          // occupied voxels noted per estimate ray (LDS: 4 bytes x 256 lanes each)
+__global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, RtFrame f, const uint32_t* work, const uint32_t* tile_list,
+                                                  uint32_t* cost, unsigned long long* cost_sum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
+    const uint32_t n = work[0];
+    if (blockIdx.x * blockDim.x >= n) return;
+    {
+        const int words = (s.grid->n_cells + 31) >> 5;
+        for (int i = threadIdx.x; i < words; i += blockDim.x) bitmap[i] = s.occupancy[i];
+        __syncthreads();
+    }
+    // The walk itself only touches LDS: the occupied voxels a ray meets are noted in a per-lane list (the first
+    // RT_EST_CELLS of them), and their triangle counts are then fetched with independent loads, several in flight,
+    // instead of one dependent memory round trip per voxel.
+    uint32_t* cells = bitmap + ((s.grid->n_cells + 31) >> 5);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = 0;
+    if (i < n) {
+        const int tile = (int)tile_list[i];
+        int x, y_local, y;
+        tile_pixel(f, tile, 27, x, y_local, y);                     // pixel (3,3) of the tile
+        if (x >= f.width || y >= f.height) tile_pixel(f, tile, 0, x, y_local, y);
+        const GridU g = load_grid(s.grid);
+        float dx, dy, dz, rayT;
+        primary_ray(cam, f, x, y, dx, dy, dz);
+        uint32_t met = 0;
+        if (grid_entry(g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, rayT)) {
+            Dda w;
+            dda_setup(w, g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, rayT);
+            bool alive = true;
+            while (alive) {
+                if ((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u) {
+                    if (met < RT_EST_CELLS) cells[met * 256 + threadIdx.x] = (uint32_t)w.cell;
+                    ++met;
+                }
+                alive = dda_advance(w, false, 0.f, 0.f);
+            }
+        }
+        const uint32_t kept = met < RT_EST_CELLS ? met : RT_EST_CELLS;
+        for (uint32_t k = 0; k < kept; k += 4) {
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t cell = cells[((k + j < kept) ? k + j : k) * 256 + threadIdx.x];
+                lo[j] = s.cell_start[cell]; hi[j] = s.cell_start[cell + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (k + j < kept) c += hi[j] - lo[j];
+        }
+        if (met > kept) c = (uint32_t)((unsigned long long)c * met / kept);     // longer walks: scaled up
+        cost[i] = c;
+    }
+    unsigned long long t = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(cost_sum, t);
+}
+
+__global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* tile_list, const uint32_t* cost,
+                                                const unsigned long long* cost_sum, uint32_t* list0, uint32_t* list1, uint32_t* list2,
+                                                float div0, float div1, int n_waves) {
+    const uint32_t n = work[0];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x * blockDim.x >= n) return;
+    // class limits: a tile is "expensive" when its estimate exceeds 1/div0 of the work one wavefront would get if the
+    // frame were spread evenly over the n_waves persistent wavefronts, "medium" above 1/div1 of it
+    const float share = (float)((double)*cost_sum / (double)n_waves);
+    const float lim0 = share / div0, lim1 = share / div1;
+    int cls = -1;
+    uint32_t tile = 0;
+    if (i < n) {
+        tile = tile_list[i];
+        const float c = (float)cost[i];
+        cls = (c > lim0) ? 0 : ((c > lim1) ? 1 : 2);
+    }
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t* lists[3] = {list0, list1, list2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const unsigned long long m = __ballot(cls == k);
+        if (!m) continue;
+        uint32_t base = 0;
+        const int first = __ffsll((long long)m) - 1;
+        if (lane == first) base = atomicAdd(&work[2 + k], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+        if (cls == k) lists[k][base + (uint32_t)__popcll(m & lt_mask)] = tile;
+    }
+}
+
 __device__ __forceinline__ float bcast_f32(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
@@ -660,6 +757,13 @@ __device__ __forceinline__ double bcast_f64(double v, int src_lane) {
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, src_lane);
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(b >> 32), src_lane);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// a*b - c*d for doubles that all hold float values: both products are exact in double (24 + 24 significant bits,
+// exponents far inside the range), so the reference's mul, mul, sub rounds once, in the subtraction, and a multiply
+// followed by one fused multiply-add rounds the same exact value once: identical bits, one instruction less.
+__device__ __forceinline__ double minor_f32(double a, double b, double c, double d) {
+    return __builtin_fma(a, b, -(c * d));
 }
 
 // One triangle record as a lane holds it during the test phase.
@@ -809,6 +913,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 if (lane == leader) { any0 = u0; any1 = u1; }      // runs some ray of this voxel needs, kept in its first lane
             }
         }
+        const long long t2 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        if (COUNT) wc.cyc_cull += (uint32_t)(t2 - t1);
         // ---- TEST: the round's (voxel, needed run) items in order: voxels by their lowest lane, runs ascending. The
         // generator runs one item ahead of the tests so that the next run's records are in flight, also across voxels.
         uint32_t sb = 0, se = 0, sorg = 0, sk = 0, snrun = 0;
@@ -864,14 +970,14 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             const uint32_t base = cur.base, e = cur.e;
             const bool have = base + lane >= cur.b && base + lane < e;
             unsigned long long lm = cur.rays & __ballot(alive);          // rays that were hit meanwhile (shadow query) drop out
-            if (COUNT) wc.lanes += (uint32_t)__popcll(__ballot(have)) * (uint32_t)__popcll(lm);
+            if (COUNT) { wc.lanes += (uint32_t)__popcll(__ballot(have)) * (uint32_t)__popcll(lm); wc.items += 1; wc.trips += (uint32_t)__popcll(lm); }
             if (lm) {
                 // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
                 double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
                 if (SHARED_ORIGIN) {
                     sx = t.v0x - ox; sy = t.v0y - oy; sz = t.v0z - oz;        // float subtractions, then widened
-                    p_e2s = t.e2y * sz - sy * t.e2z;
-                    p_e1s = t.e1y * sz - sy * t.e1z;
+                    p_e2s = minor_f32(t.e2y, sz, sy, t.e2z);
+                    p_e1s = minor_f32(t.e1y, sz, sy, t.e1z);
                 }
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
@@ -880,12 +986,12 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     if (!SHARED_ORIGIN) {
                         const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
                         sx = t.v0x - rox; sy = t.v0y - roy; sz = t.v0z - roz;
-                        p_e2s = t.e2y * sz - sy * t.e2z;
-                        p_e1s = t.e1y * sz - sy * t.e1z;
+                        p_e2s = minor_f32(t.e2y, sz, sy, t.e2z);
+                        p_e1s = minor_f32(t.e1y, sz, sy, t.e1z);
                     }
-                    const double p_e2d = t.e2y * rdz - rdy * t.e2z;
-                    const double p_e1d = t.e1y * rdz - rdy * t.e1z;
-                    const double p_sd = sy * rdz - rdy * sz;
+                    const double p_e2d = minor_f32(t.e2y, rdz, rdy, t.e2z);
+                    const double p_e1d = minor_f32(t.e1y, rdz, rdy, t.e1z);
+                    const double p_sd = minor_f32(sy, rdz, rdy, sz);
                     const double A = t.e1x * p_e2d - t.e2x * p_e1d + rdx * t.m12;
                     const double bnum = sx * p_e2d - t.e2x * p_sd - rdx * p_e2s;
                     const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
@@ -932,7 +1038,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             cur = nxt;
             more = more_next;
         }
-        if (COUNT) wc.cyc_test += (uint32_t)((long long)__builtin_amdgcn_s_memtime() - t1);
+        if (COUNT) wc.cyc_test += (uint32_t)((long long)__builtin_amdgcn_s_memtime() - t2);
     }
     return hit;
 }
@@ -944,7 +1050,7 @@ struct RtTraceArgs {
     RtFrame f;
     RtOutputs o;
     uint32_t* work;
-    const uint32_t* tile_list;
+    const uint32_t* lists[3];     // tiles per cost class, most expensive first
 };
 
 template <bool COUNT>
@@ -958,7 +1064,6 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
     (void)args_in_kernarg_segment;
     const RtTraceArgs* A = reinterpret_cast<const RtTraceArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
     uint32_t* const work = A->work;
-    const uint32_t* const tile_list = A->tile_list;
 
     const uint32_t n_listed = work[0];
     if (n_listed == 0) return;
@@ -970,29 +1075,31 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
         __syncthreads();
     }
 
-    // Work unit of a wavefront: a whole 8x8 tile (64 rays), or half (8x4) or a quarter (4x4) of one when the
-    // frame lists few tiles per wavefront, so that the longest-running tile does not set the frame time.
-    const uint32_t n_waves = gridDim.x * RT_WAVES_PER_BLOCK;
-    const int unit_shift = A->f.unit_shift;
-    const int ushift = unit_shift >= 0 ? unit_shift : ((n_listed >= 24u * n_waves) ? 0 : ((n_listed >= 12u * n_waves) ? 1 : 2));
-    const uint32_t n_units = n_listed << ushift;
-    const uint32_t batch = (uint32_t)A->f.dequeue_batch;
-    uint32_t slot = 0, slot_end = 0;
-    for (;; ++slot) {
+    // Work unit of a wavefront: a 2^-k part of an 8x8 tile (64, 32, 16 or 8 rays, Z-order blocks). The tiles come in three
+    // cost classes (k_bucket), most expensive first, and the expensive classes are cut finer, so that the long-running
+    // units start early and are spread over many wavefronts while the bulk of the frame runs as large, efficient units.
+    // queue order: q0, q1, q2 name the cost class served first, second and third
+    const int q0 = (A->f.unit_shifts >> 12) & 3, q1 = (A->f.unit_shifts >> 14) & 3, q2 = (A->f.unit_shifts >> 16) & 3;
+    const int us0 = (A->f.unit_shifts >> (8 - 4 * q0)) & 15, us1 = (A->f.unit_shifts >> (8 - 4 * q1)) & 15, us2 = (A->f.unit_shifts >> (8 - 4 * q2)) & 15;
+    const uint32_t u_end0 = work[2 + q0] << us0, u_end1 = u_end0 + (work[2 + q1] << us1), n_units = u_end1 + (work[2 + q2] << us2);
+    // frame counters are summed per wavefront and added to memory once, after the last unit
+    uint32_t acc_hits = 0, acc_shadowed = 0;
+    unsigned long long acc_ray[6] = {0, 0, 0, 0, 0, 0}, acc_w[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_cyc = 0, max_rounds = 0;
+    uint32_t slot_next = 0;
+    for (;;) {
         asm volatile("" ::: "memory");
         const RtSceneDev& s = A->s;
         const RtCamera& cam = A->cam;
         const RtShade& sh = A->sh;
         const RtFrame& f = A->f;
         const RtOutputs& o = A->o;
-        if (slot >= slot_end) {         // take the next `batch` units with one atomic
-            if (lane == 0) slot = atomicAdd(&work[1], batch);
-            slot = __builtin_amdgcn_readfirstlane(slot);
-            slot_end = slot + batch;
-        }
+        if (lane == 0) slot_next = atomicAdd(&work[1], 1u);
+        const uint32_t slot = __builtin_amdgcn_readfirstlane(slot_next);
         if (slot >= n_units) break;
-        const int tile = (int)tile_list[slot >> ushift];
-        const int sub = (int)(slot & ((1u << ushift) - 1u));
+        int ushift, tile, sub;
+        if (slot < u_end0) { ushift = us0; tile = (int)A->lists[q0][slot >> us0]; sub = (int)(slot & ((1u << us0) - 1u)); }
+        else if (slot < u_end1) { const uint32_t r = slot - u_end0; ushift = us1; tile = (int)A->lists[q1][r >> us1]; sub = (int)(r & ((1u << us1) - 1u)); }
+        else { const uint32_t r = slot - u_end1; ushift = us2; tile = (int)A->lists[q2][r >> us2]; sub = (int)(r & ((1u << us2) - 1u)); }
         // lane -> pixel of the tile: the tile's 64 pixels are numbered along a Z-order curve and unit `sub` owns
         // 64 >> ushift consecutive ones (a compact 8x8, 8x4, 4x4, 4x2 ... block); the other lanes carry no ray
         const int per_unit = 64 >> ushift;
@@ -1010,7 +1117,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
 
         // fast_trace, Serial/raytracer.cpp:71-118
         Nearest st = {INFINITY, -1};
-        WalkCount wp = {0, 0, 0, 0, 0, 0, 0, 0}, ws = {0, 0, 0, 0, 0, 0, 0, 0};
+        WalkCount wp = {}, ws = {};
         const long long t_start = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const bool hit = wave_walk<false, true, COUNT>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
                                                        sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, st, wp);
@@ -1057,37 +1164,54 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
             if (shadowed) { cr = cr * sh.shadow_scale; cg = cg * sh.shadow_scale; cb = cb * sh.shadow_scale; }
             cr = cr + colr * sh.ka; cg = cg + colg * sh.ka; cb = cb + colb * sh.ka;
         }
-        if (o.counters) {
+        {
             const unsigned long long hm = __ballot(hit), sm = __ballot(shadowed);
-            if (lane == 0) {
-                if (hm) atomicAdd(&o.counters[0], (unsigned long long)__popcll(hm));
-                if (sm) atomicAdd(&o.counters[1], (unsigned long long)__popcll(sm));
-            }
+            acc_hits += (uint32_t)__popcll(hm);
+            acc_shadowed += (uint32_t)__popcll(sm);
             if (COUNT) {
-                uint32_t v[6] = {wp.entered, wp.steps, wp.tests, ws.entered, ws.steps, ws.tests};
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    unsigned long long t = v[k];
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-                    if (lane == 0 && t) atomicAdd(&o.counters[2 + k], t);
-                }
-                if (lane == 0) {
-                    const unsigned long long cyc = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_start);
-                    atomicAdd(&o.counters[8], (unsigned long long)(wp.rounds + ws.rounds));
-                    atomicAdd(&o.counters[9], (unsigned long long)(wp.slots + ws.slots));
-                    atomicAdd(&o.counters[10], (unsigned long long)(wp.cyc_step + ws.cyc_step));
-                    atomicAdd(&o.counters[15], (unsigned long long)(wp.cyc_test + ws.cyc_test));
-                    atomicMax(&o.counters[11], cyc);
-                    atomicAdd(&o.counters[12], cyc);
-                    atomicAdd(&o.counters[13], 1ull);
-                    atomicMax(&o.counters[14], (unsigned long long)(wp.rounds + ws.rounds));
-                    atomicAdd(&o.counters[16], (unsigned long long)wp.lanes + (unsigned long long)ws.lanes);
-                    if (o.unit_cost) o.unit_cost[slot] = (uint32_t)cyc;
-                }
+                const unsigned long long cyc = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_start);
+                acc_ray[0] += wp.entered; acc_ray[1] += wp.steps; acc_ray[2] += wp.tests;
+                acc_ray[3] += ws.entered; acc_ray[4] += ws.steps; acc_ray[5] += ws.tests;
+                acc_w[0] += wp.rounds + ws.rounds; acc_w[1] += wp.slots + ws.slots; acc_w[2] += wp.cyc_step + ws.cyc_step;
+                acc_w[3] += wp.cyc_test + ws.cyc_test; acc_w[4] += cyc; acc_w[5] += 1;
+                acc_w[6] += (unsigned long long)wp.lanes + ws.lanes; acc_w[7] += wp.items + ws.items; acc_w[8] += wp.trips + ws.trips;
+                acc_w[9] += wp.cyc_cull + ws.cyc_cull;
+                if (cyc > max_cyc) max_cyc = cyc;
+                if (wp.rounds + ws.rounds > max_rounds) max_rounds = wp.rounds + ws.rounds;
+                if (lane == 0 && o.unit_cost) o.unit_cost[slot] = (uint32_t)cyc;
             }
         }
         if (in_unit) write_pixel(f, o, x, y_local, cr, cg, cb, id);
+    }
+    unsigned long long* const counters = A->o.counters;
+    if (counters) {
+        if (lane == 0) {
+            if (acc_hits) atomicAdd(&counters[0], (unsigned long long)acc_hits);
+            if (acc_shadowed) atomicAdd(&counters[1], (unsigned long long)acc_shadowed);
+        }
+        if (COUNT) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                unsigned long long t = acc_ray[k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+                if (lane == 0 && t) atomicAdd(&counters[2 + k], t);
+            }
+            if (lane == 0) {
+                atomicAdd(&counters[8], acc_w[0]);
+                atomicAdd(&counters[9], acc_w[1]);
+                atomicAdd(&counters[10], acc_w[2]);
+                atomicAdd(&counters[15], acc_w[3]);
+                atomicMax(&counters[11], max_cyc);
+                atomicAdd(&counters[12], acc_w[4]);
+                atomicAdd(&counters[13], acc_w[5]);
+                atomicMax(&counters[14], max_rounds);
+                atomicAdd(&counters[16], acc_w[6]);
+                atomicAdd(&counters[17], acc_w[7]);
+                atomicAdd(&counters[18], acc_w[8]);
+                atomicAdd(&counters[19], acc_w[9]);
+            }
+        }
     }
 }
 
@@ -1102,8 +1226,14 @@ hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, R
     int blocks = wk.n_cu * wk.blocks_per_cu;
     const int max_useful = (tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK;
     if (blocks > max_useful) blocks = max_useful;
+    if (n_cls > 0 && s.n_tris > 0) {
+        const int nb = (n_cls + 255) / 256;
+        k_estimate<<<nb, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum);
+        k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.list[0], wk.list[1], wk.list[2], wk.thr0, wk.thr1, blocks * RT_WAVES_PER_BLOCK);
+    }
     RtTraceArgs ta;
-    ta.s = s; ta.cam = cam; ta.sh = sh; ta.f = f; ta.o = o; ta.work = wk.work; ta.tile_list = wk.tile_list;
+    ta.s = s; ta.cam = cam; ta.sh = sh; ta.f = f; ta.o = o; ta.work = wk.work;
+    ta.lists[0] = wk.list[0]; ta.lists[1] = wk.list[1]; ta.lists[2] = wk.list[2];
     if (f.count_work) k_trace<true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     else k_trace<false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     return hipGetLastError();

@@ -14,7 +14,8 @@ for w in sys.argv[1:]:
     print(w, "ms_render(count)", round(st["ms_render"], 3), "tiles", st["tiles_traced"], "rounds/tile", round(st["sched_rounds"] / t, 1),
           "max rounds", st["tile_rounds_max"], "streams/round", round(st["sched_streams"] / r, 2), "cyc step/tile", int(st["sched_lanes"] / t), "cyc test/tile", int(st["cycles_test"] / t),
           "tile cycles avg", int(st["tile_cycles_sum"] / t), "max", st["tile_cycles_max"],
-          "tests", st["tests_primary"] + st["tests_shadow"], "executed", st["tests_executed"], "steps", st["steps_primary"] + st["steps_shadow"])
+          "tests", st["tests_primary"] + st["tests_shadow"], "executed", st["tests_executed"], "steps", st["steps_primary"] + st["steps_shadow"],
+          "| runs", st["runs_streamed"], "trips", st["run_ray_trips"], "cyc cull/tile", int(st["cycles_cull"] / t))
     import numpy as np
     c = scene.unit_costs(((W + 7) // 8) * ((H + 7) // 8) * 64)
     c = c[c > 0].astype(np.float64)
