@@ -102,7 +102,8 @@ struct RtBuildDev {
 hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh, RtBuildDev b, hipStream_t st);
 hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st);   // init, bounds, setup, count, scan -> grid.n_refs known
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st);   // scatter, per-cell order, record emit
-hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st);
+hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtFrame f, RtRenderWork wk, hipStream_t st);   // classify, estimate, cost classes
+hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st);
 size_t rt_trace_lds_bytes(int bitmap_words);
 hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32_t n_refs, hipStream_t st);
 hipError_t rt_launch_deinterleave(const void* src, void* dst, int32_t width, int32_t height, int32_t part_count,

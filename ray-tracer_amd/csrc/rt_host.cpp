@@ -87,6 +87,8 @@ struct rt_scene {
     float sched_thr0 = 1.5f, sched_thr1 = 8.f;
     int sched_shifts = (2 << 8) | (2 << 4) | 0 | (0 << 12) | (2 << 14) | (1 << 16);   // shifts of class 0,1,2; queue order in bits 12..17
     hipStream_t last_stream = nullptr;
+    hipStream_t side_stream = nullptr;       // work-list preparation beside the grid build
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     rt_params last_params;
 };
 
@@ -117,6 +119,9 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); for (auto& l : s->cls_list) l.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
         for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
+        if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+        if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+        if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
     }
     delete s;
 }
@@ -295,6 +300,9 @@ static int scene_bind_device(rt_scene* s) {
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         for (auto& slot : s->ev) for (auto& ev : slot) HIP_TRY(hipEventCreate(&ev));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
     }
     return RT_OK;
 }
@@ -348,7 +356,8 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     return RT_OK;
 }
 
-static int build_grid_async(rt_scene* s, hipStream_t st) {
+// `after_phase1`, when given, is recorded once cell_start and the occupancy bitmap are final (the records are not yet).
+static int build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_phase1 = nullptr) {
     int rc;
     if (!s->refs_known) {
         // First build of this triangle list: run count + scan, read the reference total back once and size
@@ -366,6 +375,7 @@ static int build_grid_async(rt_scene* s, hipStream_t st) {
     } else {
         HIP_TRY(rt_launch_build_phase1(build_args(s), st));
     }
+    if (after_phase1) HIP_TRY(hipEventRecord(after_phase1, st));
     HIP_TRY(rt_launch_build_phase2(build_args(s), st));
     s->grid_valid = true;
     return RT_OK;
@@ -463,12 +473,17 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     const int slot = (int)(s->frames % RT_STATS_RING);
     HIP_TRY(hipEventRecord(s->ev[slot][0], st));
     s->built[slot] = false;
-    if (rebuild_grid || !s->grid_valid) {
-        if ((rc = build_grid_async(s, st))) return rc;
+    // With a grid build in the frame, everything that only needs the grid's cell table (clearing the outputs, the tile list
+    // and its cost classes) runs on a side stream beside the second half of the build and joins before the trace kernel.
+    const bool rebuild = rebuild_grid || !s->grid_valid;
+    hipStream_t side = st;
+    if (rebuild) {
+        if ((rc = build_grid_async(s, st, s->ev_fork))) return rc;
         s->built[slot] = true;
+        side = s->side_stream;
+        HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
     }
-    HIP_TRY(hipEventRecord(s->ev[slot][1], st));
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 32 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 32 * sizeof(unsigned long long), side));
 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
@@ -494,9 +509,9 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     o.unit_cost = nullptr;
     // background everywhere first: black, no hit
     const size_t out_px = (size_t)p->width * (size_t)f.out_rows;
-    if (o.rgb_f32) HIP_TRY(hipMemsetAsync(o.rgb_f32, 0, out_px * 3 * sizeof(float), st));
-    if (o.rgb_u8) HIP_TRY(hipMemsetAsync(o.rgb_u8, 0, out_px * 3, st));
-    if (o.hit_id) HIP_TRY(hipMemsetAsync(o.hit_id, 0xff, out_px * sizeof(int32_t), st));
+    if (o.rgb_f32) HIP_TRY(hipMemsetAsync(o.rgb_f32, 0, out_px * 3 * sizeof(float), side));
+    if (o.rgb_u8) HIP_TRY(hipMemsetAsync(o.rgb_u8, 0, out_px * 3, side));
+    if (o.hit_id) HIP_TRY(hipMemsetAsync(o.hit_id, 0xff, out_px * sizeof(int32_t), side));
     const RtCamera cam = make_camera(p);
     RtRenderWork wk;
     {
@@ -515,7 +530,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         if ((rc = s->tile_list.ensure(tiles ? tiles : 1))) return rc;
         if (s->count_work) {
             if ((rc = s->unit_cost.ensure((tiles ? tiles : 1) * 64))) return rc;
-            HIP_TRY(hipMemsetAsync(s->unit_cost.p, 0, (tiles ? tiles : 1) * 64 * sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(s->unit_cost.p, 0, (tiles ? tiles : 1) * 64 * sizeof(uint32_t), side));
             o.unit_cost = s->unit_cost.p;
         }
         wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 24);
@@ -535,7 +550,13 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         wk.blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
 
     }
-    HIP_TRY(rt_launch_render(sd, cam, sh, f, o, wk, st));
+    HIP_TRY(rt_launch_render_prep(sd, cam, f, wk, side));
+    if (side != st) {
+        HIP_TRY(hipEventRecord(s->ev_join, side));
+        HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
+    }
+    HIP_TRY(hipEventRecord(s->ev[slot][1], st));
+    HIP_TRY(rt_launch_trace(sd, cam, sh, f, o, wk, st));
     HIP_TRY(hipEventRecord(s->ev[slot][2], st));
     s->frames++;
     s->last_stream = st;

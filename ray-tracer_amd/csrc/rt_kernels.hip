@@ -648,6 +648,22 @@ __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t
     return true;
 }
 
+// Occupancy bitmap of the grid into LDS, all loads of a thread in flight together (16 bytes each).
+__device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* occupancy, int words) {
+    const int quads = words >> 2;
+    const uint4* src = reinterpret_cast<const uint4*>(occupancy);
+    uint4* dst = reinterpret_cast<uint4*>(bitmap);
+    for (int i = threadIdx.x; i < quads; i += 4 * blockDim.x) {
+        uint4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = i + j * (int)blockDim.x; q[j] = src[k < quads ? k : i]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int k = i + j * (int)blockDim.x; if (k < quads) dst[k] = q[j]; }
+    }
+    for (int i = (quads << 2) + threadIdx.x; i < words; i += blockDim.x) bitmap[i] = occupancy[i];
+    __syncthreads();
+}
+
 // COST ESTIMATE per listed tile: the ray of the tile's centre pixel is walked through the whole grid (no triangle
 // tests) and the triangle counts of the occupied voxels it visits are summed. Tiles whose rays graze the surface or
 // cross crowded voxels get a large estimate; they are queued first and cut into smaller work units (k_bucket), so the
@@ -660,11 +676,7 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
     const uint32_t n = work[0];
     if (blockIdx.x * blockDim.x >= n) return;
-    {
-        const int words = (s.grid->n_cells + 31) >> 5;
-        for (int i = threadIdx.x; i < words; i += blockDim.x) bitmap[i] = s.occupancy[i];
-        __syncthreads();
-    }
+    bitmap_to_lds(bitmap, s.occupancy, (s.grid->n_cells + 31) >> 5);
     // The walk itself only touches LDS: the occupied voxels a ray meets are noted in a per-lane list (the first
     // RT_EST_CELLS of them), and their triangle counts are then fetched with independent loads, several in flight,
     // instead of one dependent memory round trip per voxel.
@@ -1070,9 +1082,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
     {
         const RtSceneDev& s = A->s;
         // occupancy bitmap of the whole grid into LDS, once per block
-        const int words = (s.grid->n_cells + 31) >> 5;
-        for (int i = threadIdx.x; i < words; i += blockDim.x) bitmap[i] = s.occupancy[i];
-        __syncthreads();
+        bitmap_to_lds(bitmap, s.occupancy, (s.grid->n_cells + 31) >> 5);
     }
 
     // Work unit of a wavefront: a 2^-k part of an 8x8 tile (64, 32, 16 or 8 rays, Z-order blocks). The tiles come in three
@@ -1215,22 +1225,31 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
     }
 }
 
-hipError_t rt_launch_render(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st) {
+static int trace_blocks(const RtFrame& f, const RtRenderWork& wk) {
     const int tiles_x = (f.width + RT_TILE - 1) / RT_TILE;
     const int tiles_y = (f.out_rows + RT_TILE - 1) / RT_TILE;
     const int tiles = tiles_x * tiles_y;
-    if (tiles <= 0) return hipSuccess;
-    const int n_cls = wk.ntx * wk.ntb;
-    if (n_cls > 0 && s.n_tris > 0) k_classify<<<(n_cls + 4 * RT_CLS_TILES_PER_WAVE - 1) / (4 * RT_CLS_TILES_PER_WAVE), 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
-    const size_t lds = rt_trace_lds_bytes(wk.bitmap_words);
     int blocks = wk.n_cu * wk.blocks_per_cu;
     const int max_useful = (tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK;
-    if (blocks > max_useful) blocks = max_useful;
-    if (n_cls > 0 && s.n_tris > 0) {
-        const int nb = (n_cls + 255) / 256;
-        k_estimate<<<nb, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum);
-        k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.list[0], wk.list[1], wk.list[2], wk.thr0, wk.thr1, blocks * RT_WAVES_PER_BLOCK);
-    }
+    return blocks > max_useful ? max_useful : blocks;
+}
+
+// Work list of a frame: tiles that see the grid, their cost estimates and cost classes. Needs the grid's cell_start and
+// occupancy, not the triangle records, so it can run beside the second half of a grid build.
+hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtFrame f, RtRenderWork wk, hipStream_t st) {
+    const int n_cls = wk.ntx * wk.ntb;
+    if (n_cls <= 0 || s.n_tris == 0) return hipSuccess;
+    k_classify<<<(n_cls + 4 * RT_CLS_TILES_PER_WAVE - 1) / (4 * RT_CLS_TILES_PER_WAVE), 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
+    const int nb = (n_cls + 255) / 256;
+    k_estimate<<<nb, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum);
+    k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.list[0], wk.list[1], wk.list[2], wk.thr0, wk.thr1, trace_blocks(f, wk) * RT_WAVES_PER_BLOCK);
+    return hipGetLastError();
+}
+
+hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st) {
+    const int blocks = trace_blocks(f, wk);
+    if (blocks <= 0) return hipSuccess;
+    const size_t lds = rt_trace_lds_bytes(wk.bitmap_words);
     RtTraceArgs ta;
     ta.s = s; ta.cam = cam; ta.sh = sh; ta.f = f; ta.o = o; ta.work = wk.work;
     ta.lists[0] = wk.list[0]; ta.lists[1] = wk.list[1]; ta.lists[2] = wk.list[2];
