@@ -305,14 +305,43 @@ __device__ __forceinline__ void emit_record(const RtBuildDev& b, uint32_t tri, u
     o[2] = make_float4(e2x, e2y, e2z, __uint_as_float((uint32_t)(mb >> 32)));
 }
 
-#define RT_ORDER_LDS_IDS 2048          // triangle indices of one voxel a wavefront holds in LDS at a time
+#define RT_ORDER_LDS_IDS 1024          // triangle indices of one voxel a wavefront holds in LDS at a time (16 rows)
+
+// ROW SORT: every aligned row of 64 references is sorted by (voxel, triangle index) inside its wavefront (bitonic
+// network over the lanes). References are already grouped by voxel, so a voxel's references keep their places in the
+// row and only their order inside the voxel's part of the row changes.
+__global__ void __launch_bounds__(256) k_row_sort(RtBuildDev b) {
+    const uint32_t n_refs = b.grid->n_refs;
+    if (n_refs > b.ref_cap) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_rows = (n_refs + 63u) / 64u;
+    for (uint32_t row = wave; row < n_rows; row += n_waves) {
+        const uint32_t p = row * 64u + lane;
+        unsigned long long key = ~0ull;
+        if (p < n_refs) key = ((unsigned long long)b.ref_cell[p] << 32) | b.ref_tri[p];
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const unsigned long long other = __shfl_xor(key, j);
+                const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+                const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+                key = (lower == up) ? mn : mx;
+            }
+        }
+        if (p < n_refs) b.ref_tri[p] = (uint32_t)key;
+    }
+}
 
 // ORDER + EMIT: the reference appends triangles to a voxel in ascending index (Serial/grid.h:118-150) and the
-// first-tested triangle wins ties, so every voxel's list is put back into ascending order: each reference
-// counts the smaller indices in its voxel (indices are distinct) and writes its 48-byte record at that rank.
-// A wavefront takes 64 consecutive references. For every voxel these belong to, the voxel's index list is
-// streamed through LDS in tiles and the lanes of that voxel count against it; a crowded voxel is therefore
-// shared out over as many wavefronts as it has 64-reference rows.
+// first-tested triangle wins ties, so every voxel's list is put back into ascending order: each reference finds its
+// rank = the number of smaller indices in its voxel (indices are distinct) and writes its 48-byte record there.
+// A wavefront takes one row of 64 references. For every voxel these belong to, the voxel's index list is streamed
+// through LDS in tiles of whole rows; the rows are sorted (k_row_sort), so the number of smaller indices in a row is a
+// 7-probe binary search, and a crowded voxel is shared out over as many wavefronts as it has rows.
+// LDS holds index + 1; places of the first row that belong to the previous voxel hold 0 (always counted, and taken
+// off again), places after the voxel's end hold 0xffffffff (never counted).
 __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
     __shared__ __attribute__((aligned(16))) uint32_t ids_all[4][RT_ORDER_LDS_IDS];
     const uint32_t n_refs = b.grid->n_refs;
@@ -326,6 +355,7 @@ __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
         const bool valid = p < n_refs;
         uint32_t c = 0xffffffffu, me = 0, beg = 0, end = 0;
         if (valid) { c = b.ref_cell[p]; me = b.ref_tri[p]; beg = b.cell_start[c]; end = b.cell_start[c + 1]; }
+        const uint32_t me1 = me + 1u;
         uint32_t rank = 0;
         unsigned long long rem = __ballot(valid);
         while (rem) {
@@ -335,15 +365,39 @@ __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
             const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)end, l);
             const bool mem = valid && c == c0;
             rem &= ~__ballot(mem);
-            for (uint32_t tile = b0; tile < e0; tile += RT_ORDER_LDS_IDS) {
-                const uint32_t nt = (e0 - tile) < RT_ORDER_LDS_IDS ? (e0 - tile) : RT_ORDER_LDS_IDS;
-                const uint32_t nt4 = (nt + 3u) & ~3u;
-                for (uint32_t k = lane; k < nt4; k += 64) ids[k] = (k < nt) ? b.ref_tri[tile + k] : 0xffffffffu;
+            const uint32_t first = b0 & ~63u;
+            if (mem) rank -= b0 - first;
+            for (uint32_t tile = first; tile < e0; tile += RT_ORDER_LDS_IDS) {
+                const uint32_t nt = (((e0 - tile) < RT_ORDER_LDS_IDS ? (e0 - tile) : RT_ORDER_LDS_IDS) + 63u) & ~63u;   // whole rows
+                for (uint32_t k = lane; k < nt; k += 64) {
+                    const uint32_t q = tile + k;
+                    ids[k] = (q < b0) ? 0u : ((q < e0) ? b.ref_tri[q] + 1u : 0xffffffffu);
+                }
                 __builtin_amdgcn_wave_barrier();
                 if (mem) {
-                    for (uint32_t j = 0; j < nt4; j += 4) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(ids + j);
-                        rank += (v.x < me) + (v.y < me) + (v.z < me) + (v.w < me);
+                    // four rows per trip: independent probe chains
+                    uint32_t r = 0;
+                    for (; r + 256u <= nt; r += 256u) {
+                        const uint32_t* sr = ids + r;
+                        uint32_t n0 = 0, n1 = 64, n2 = 128, n3 = 192;
+#pragma unroll
+                        for (uint32_t st = 32; st > 0; st >>= 1) {
+                            const uint32_t v0 = sr[n0 + st - 1u], v1 = sr[n1 + st - 1u], v2 = sr[n2 + st - 1u], v3 = sr[n3 + st - 1u];
+                            n0 += (v0 < me1) ? st : 0u;
+                            n1 += (v1 < me1) ? st : 0u;
+                            n2 += (v2 < me1) ? st : 0u;
+                            n3 += (v3 < me1) ? st : 0u;
+                        }
+                        const uint32_t v0 = sr[n0], v1 = sr[n1], v2 = sr[n2], v3 = sr[n3];
+                        rank += (n0 + n1 + n2 + n3 - 384u) + (v0 < me1) + (v1 < me1) + (v2 < me1) + (v3 < me1);
+                    }
+                    for (; r < nt; r += 64u) {
+                        const uint32_t* s0 = ids + r;
+                        uint32_t n0 = 0;
+#pragma unroll
+                        for (uint32_t st = 32; st > 0; st >>= 1) n0 += (s0[n0 + st - 1u] < me1) ? st : 0u;
+                        n0 += (s0[n0] < me1) ? 1u : 0u;
+                        rank += n0;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -406,7 +460,8 @@ hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st) {
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st) {
     if (b.n_tris == 0) return hipSuccess;
     k_scatter<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
-    k_order_emit<<<1024, 256, 0, st>>>(b);
+    k_row_sort<<<1024, 256, 0, st>>>(b);
+    k_order_emit<<<2048, 256, 0, st>>>(b);
     k_block_bounds<<<1024, 256, 0, st>>>(b);
     return hipGetLastError();
 }
