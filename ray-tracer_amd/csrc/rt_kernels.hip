@@ -1026,14 +1026,9 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             const float4* r = s.recs + 3ull * ((p >= it.b && p < it.e) ? p : it.b);
             r0 = r[0]; r1 = r[1]; r2 = r[2];
         };
-        Item cur, nxt;
-        float4 n0, n1, n2;
-        bool more = next_item(cur);
-        if (more) load_item(cur, n0, n1, n2);
-        while (more) {
-            const TriRec t = unpack_rec(n0, n1, n2);
-            const bool more_next = next_item(nxt);
-            if (more_next) load_item(nxt, n0, n1, n2);
+        // Two runs are kept in flight: the records of item i+2 are requested before item i is tested, so a load has the
+        // time of two items' tests to arrive (slots A and B take turns).
+        auto process = [&](const Item& cur, const TriRec& t) {
             const uint32_t base = cur.base, e = cur.e;
             const bool have = base + lane >= cur.b && base + lane < e;
             unsigned long long lm = cur.rays & __ballot(alive);          // rays that were hit meanwhile (shadow query) drop out
@@ -1102,8 +1097,29 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     }
                 }
             }
-            cur = nxt;
-            more = more_next;
+        };
+        Item itA, itB;
+        float4 a0, a1, a2, b0, b1, b2;
+        bool hA = next_item(itA);
+        if (hA) load_item(itA, a0, a1, a2);
+        bool hB = hA && next_item(itB);
+        if (hB) load_item(itB, b0, b1, b2);
+        while (hA) {
+            {
+                const TriRec t = unpack_rec(a0, a1, a2);
+                const Item cur = itA;
+                hA = hB && next_item(itA);
+                if (hA) load_item(itA, a0, a1, a2);
+                process(cur, t);
+            }
+            if (!hB) break;
+            {
+                const TriRec t = unpack_rec(b0, b1, b2);
+                const Item cur = itB;
+                hB = hA && next_item(itB);
+                if (hB) load_item(itB, b0, b1, b2);
+                process(cur, t);
+            }
         }
         if (COUNT) wc.cyc_test += (uint32_t)((long long)__builtin_amdgcn_s_memtime() - t2);
     }
