@@ -80,7 +80,9 @@ typedef struct rt_frame_stats {
         tests_executed /* triangle tests actually run: runs whose box the ray's line misses are skipped */,
         runs_streamed /* 64-record runs read by wavefronts */,
         run_ray_trips /* (run, ray) iterations of the test loop */,
-        cycles_cull /* cycles in the run culling */;
+        cycles_cull /* cycles in the run culling */,
+        wave_cycles_max /* busiest wavefront: cycles inside work units */,
+        span_cycles /* first wavefront start to last wavefront end */;
 } rt_frame_stats;
 
 const char* rt_last_error(void);

@@ -47,6 +47,7 @@ class FrameStats(C.Structure):
         ("tile_cycles_max", C.c_uint64), ("tile_cycles_sum", C.c_uint64), ("tiles_traced", C.c_uint64),
         ("tile_rounds_max", C.c_uint64), ("cycles_test", C.c_uint64), ("tests_executed", C.c_uint64),
         ("runs_streamed", C.c_uint64), ("run_ray_trips", C.c_uint64), ("cycles_cull", C.c_uint64),
+        ("wave_cycles_max", C.c_uint64), ("span_cycles", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -8,6 +8,8 @@
 #define RT_MAX_CELLS (64 * 64 * 64)
 #define RT_SCAN_CHUNK 1024                         // cells per scan block
 #define RT_MAX_SCAN_BLOCKS (RT_MAX_CELLS / RT_SCAN_CHUNK)
+#define RT_WORK_LIST_COUNTS 32                     // first work[] word of the per-list tile counts (128 bytes after the head)
+#define RT_QUEUE_LISTS 16                          // tile lists the trace kernel serves in order (cost classes)
 
 // Grid description, resident in device memory: k_grid_setup writes the geometry, k_scan_apply writes n_refs.
 struct RtGrid {
@@ -40,7 +42,7 @@ struct RtFrame {
     int32_t walk_full;            // 1 = walk every primary ray to the grid exit
     float early_slack;
     int32_t count_work;           // 1 = the kernel also counts voxel steps and triangle tests
-    int32_t unit_shifts;          // 4 bits per cost class (class 0 in bits 8..11): log2 of the units a tile is cut into
+    uint64_t unit_shifts;         // 4 bits per queue list (list 0 lowest): log2 of the work units a tile of the list is cut into
     int32_t cull_min;             // voxels with at least this many triangles get the per-run box test
 };
 
@@ -63,16 +65,21 @@ struct RtOutputs {
     uint8_t* rgb_u8;
     int32_t* hit_id;
     uint32_t* unit_cost;          // counting build only: shader cycles of every work unit, in queue order (may be NULL)
+    uint32_t* tile_cycles;        // counting build only: shader cycles per tile of the frame, summed over its units (may be NULL)
     unsigned long long* counters; // [0] hits, [1] shadowed, [2..4] primary entered/steps/tests, [5..7] shadow entered/steps/tests
 };
 
 // Per-frame work list of the render kernels.
 struct RtRenderWork {
-    uint32_t* work;               // [0] listed tiles, [1] dequeue head, [2..4] tiles per cost class; zeroed before each frame
+    uint32_t* work;               // [0] listed tiles, [1] dequeue head, [RT_WORK_LIST_COUNTS..+15] tiles per queue list; zeroed before each frame
     uint32_t* tile_list;          // capacity = tiles of the frame
     uint32_t* cost;               // estimated cost per listed tile
+    uint32_t* est_by_tile;        // diagnostics: the four estimate features, each indexed by tile of the frame (may be NULL)
+    int32_t n_tiles;              // tiles of the frame
+    float est_w[4];               // estimate weights: primary triangles, primary voxels, shadow triangles, shadow voxels
     unsigned long long* cost_sum; // zeroed before each frame
-    uint32_t* list[3];            // tiles per cost class (0 = most expensive), capacity = tiles of the frame each
+    uint32_t* lists;              // RT_QUEUE_LISTS tile lists in queue order, list_cap entries each
+    uint32_t list_cap;            // = tiles of the frame
     float thr0, thr1;             // class limits: 1/thr0 and 1/thr1 of a wavefront's even share of the frame's estimate
     int32_t bitmap_words;         // LDS words reserved for the occupancy bitmap (>= ceil(n_cells / 32))
     int32_t n_cu, blocks_per_cu;
@@ -102,7 +109,7 @@ struct RtBuildDev {
 hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh, RtBuildDev b, hipStream_t st);
 hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st);   // init, bounds, setup, count, scan -> grid.n_refs known
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st);   // scatter, per-cell order, record emit
-hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtFrame f, RtRenderWork wk, hipStream_t st);   // classify, estimate, cost classes
+hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtRenderWork wk, hipStream_t st);   // classify, estimate, cost classes
 hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st);
 size_t rt_trace_lds_bytes(int bitmap_words);
 hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32_t n_refs, hipStream_t st);

@@ -69,8 +69,8 @@ struct rt_scene {
     DevBuf<RtGrid> d_grid;
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
     DevBuf<float4> recs, blk_bounds;
-    DevBuf<unsigned long long> counters;   // 20 frame counters + one 8-byte slot holding the two work-list words
-    DevBuf<uint32_t> tile_list, unit_cost, tile_cost, cls_list[3];
+    DevBuf<unsigned long long> counters;   // 24 frame counters, then the work-list words (RtRenderWork::work)
+    DevBuf<uint32_t> tile_list, unit_cost, tile_cost, queue_lists;
     int n_cu = 0;
     uint32_t known_cells = 0;              // n_cells of the current triangle list once measured
     RtGrid h_grid;                         // grid description of the current triangle list once measured
@@ -82,10 +82,12 @@ struct rt_scene {
     bool built[RT_STATS_RING] = {};
     uint64_t frames = 0;               // frames rendered so far; frame k uses ring slot k % RT_STATS_RING
     bool count_work = false;
-    // scheduling of the trace kernel: a tile is in cost class 0 (1) when its estimate exceeds 1/thr0 (1/thr1) of the even
-    // share of one wavefront; log2 of the work units a tile of each class is cut into, and the queue order of the classes
-    float sched_thr0 = 1.5f, sched_thr1 = 8.f;
-    int sched_shifts = (2 << 8) | (2 << 4) | 0 | (0 << 12) | (2 << 14) | (1 << 16);   // shifts of class 0,1,2; queue order in bits 12..17
+    // scheduling of the trace kernel: a tile is "expensive" when its estimate exceeds 1/thr0 of the even share of one
+    // wavefront and "cheap" below 1/thr1 of it; unit_shifts holds log2 of the work units a tile is cut into, 4 bits per
+    // queue list (expensive 0..7 from the top down, cheap 8..11, in-between 12..15)
+    float sched_thr0 = 1.f, sched_thr1 = 8.f;
+    uint64_t sched_shifts = 0x2222000022223333ull;
+    float est_w[4] = {1.f, 500.f, 0.f, 700.f};    // cost estimate weights: primary triangles, primary voxels, shadow triangles, shadow voxels
     hipStream_t last_stream = nullptr;
     hipStream_t side_stream = nullptr;       // work-list preparation beside the grid build
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -96,15 +98,15 @@ extern "C" rt_scene* rt_scene_create(void) {
     rt_scene* s = new (std::nothrow) rt_scene();
     if (s) memset(&s->last_params, 0, sizeof(s->last_params));
     if (s) {
-        // experiment override: RT_SCHED="thr0:thr1:shift0:shift1:shift2[:order]", order = the three class digits in queue order
-        const char* e = getenv("RT_SCHED");
-        float a, b; int u0, u1, u2, ord = 12;
-        if (e && sscanf(e, "%f:%f:%d:%d:%d:%d", &a, &b, &u0, &u1, &u2, &ord) >= 5 && u0 >= 0 && u0 <= 6 && u1 >= 0 && u1 <= 6 && u2 >= 0 && u2 <= 6) {
-            const int o0 = (ord / 100) % 10, o1 = (ord / 10) % 10, o2 = ord % 10;
-            if (o0 < 3 && o1 < 3 && o2 < 3 && o0 != o1 && o0 != o2 && o1 != o2) {
-                s->sched_thr0 = a; s->sched_thr1 = b;
-                s->sched_shifts = (u0 << 8) | (u1 << 4) | u2 | (o0 << 12) | (o1 << 14) | (o2 << 16);
-            }
+        if (const char* ew = getenv("RT_EST_W")) { float w[4]; if (sscanf(ew, "%f:%f:%f:%f", &w[0], &w[1], &w[2], &w[3]) == 4) for (int k = 0; k < 4; ++k) s->est_w[k] = w[k]; }
+        // experiment overrides: RT_SCHED="thr0:thr1", RT_SHIFTS=16 hex digits, list 15 first
+        if (const char* e = getenv("RT_SCHED")) { float a, b; if (sscanf(e, "%f:%f", &a, &b) == 2 && a > 0 && b >= a) { s->sched_thr0 = a; s->sched_thr1 = b; } }
+        if (const char* e = getenv("RT_SHIFTS")) {
+            char* end = nullptr;
+            const unsigned long long v = strtoull(e, &end, 16);
+            bool ok = end && *end == 0;
+            for (int k = 0; k < 16 && ok; ++k) ok = ((v >> (4 * k)) & 15ull) <= 4;
+            if (ok) s->sched_shifts = v;
         }
     }
     return s;
@@ -116,7 +118,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         (void)hipSetDevice(s->device);
         s->v0.release(); s->v1.release(); s->v2.release(); s->d_mesh_color.release(); s->d_grid.release();
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
-        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); for (auto& l : s->cls_list) l.release();
+        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); s->queue_lists.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
         for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
         if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -332,7 +334,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
-        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(32)))
+        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(56)))
         return rc;
     HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
     HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
@@ -483,7 +485,8 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         side = s->side_stream;
         HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
     }
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 32 * sizeof(unsigned long long), side));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 56 * sizeof(unsigned long long), side));
+    if (s->count_work) HIP_TRY(hipMemsetAsync(s->counters.p + 22, 0xff, sizeof(unsigned long long), side));   // slot of a minimum
 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
@@ -506,7 +509,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;
-    o.unit_cost = nullptr;
+    o.unit_cost = nullptr; o.tile_cycles = nullptr;
     // background everywhere first: black, no hit
     const size_t out_px = (size_t)p->width * (size_t)f.out_rows;
     if (o.rgb_f32) HIP_TRY(hipMemsetAsync(o.rgb_f32, 0, out_px * 3 * sizeof(float), side));
@@ -514,6 +517,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     if (o.hit_id) HIP_TRY(hipMemsetAsync(o.hit_id, 0xff, out_px * sizeof(int32_t), side));
     const RtCamera cam = make_camera(p);
     RtRenderWork wk;
+    wk.est_by_tile = nullptr;
     {
         // tiles that can see the grid: full-frame tile rows ty0..ty1 -> local bands of this part
         int tx0, tx1, ty0, ty1;
@@ -531,14 +535,18 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         if (s->count_work) {
             if ((rc = s->unit_cost.ensure((tiles ? tiles : 1) * 64))) return rc;
             HIP_TRY(hipMemsetAsync(s->unit_cost.p, 0, (tiles ? tiles : 1) * 64 * sizeof(uint32_t), side));
-            o.unit_cost = s->unit_cost.p;
+            // layout: 16 x tiles unit slots, then the four estimate features and the measured cycles of every tile of the frame
+            o.unit_cost = s->unit_cost.p; o.tile_cycles = s->unit_cost.p + 20 * tiles; wk.est_by_tile = s->unit_cost.p + 16 * tiles;
         }
         wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 24);
         wk.cost_sum = s->counters.p + 20;
         if ((rc = s->tile_cost.ensure(tiles ? tiles : 1))) return rc;
         wk.cost = s->tile_cost.p;
-        for (int k = 0; k < 3; ++k) { if ((rc = s->cls_list[k].ensure(tiles ? tiles : 1))) return rc; wk.list[k] = s->cls_list[k].p; }
+        if ((rc = s->queue_lists.ensure((tiles ? tiles : 1) * RT_QUEUE_LISTS))) return rc;
+        wk.lists = s->queue_lists.p; wk.list_cap = (uint32_t)(tiles ? tiles : 1);
         wk.thr0 = s->sched_thr0; wk.thr1 = s->sched_thr1;
+        wk.n_tiles = (int32_t)tiles;
+        for (int k = 0; k < 4; ++k) wk.est_w[k] = s->est_w[k];
         wk.tile_list = s->tile_list.p;
         // LDS for the occupancy bitmap: exact once the grid of this triangle list has been measured
         const uint32_t cells = s->refs_known ? s->known_cells : (uint32_t)RT_MAX_CELLS;
@@ -550,7 +558,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         wk.blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
 
     }
-    HIP_TRY(rt_launch_render_prep(sd, cam, f, wk, side));
+    HIP_TRY(rt_launch_render_prep(sd, cam, sh, f, wk, side));
     if (side != st) {
         HIP_TRY(hipEventRecord(s->ev_join, side));
         HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
@@ -615,7 +623,7 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     HIP_TRY(hipEventElapsedTime(&out->ms_total, ev[0], ev[2]));
     if (!s->built[slot]) out->ms_build = 0.f;
     RtGrid g;
-    unsigned long long c[20];
+    unsigned long long c[24];
     HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
     for (int a = 0; a < 3; ++a) out->grid_n[a] = g.n[a];
@@ -639,6 +647,7 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     out->sched_rounds = c[8]; out->sched_streams = c[9]; out->sched_lanes = c[10];
     out->tile_cycles_max = c[11]; out->tile_cycles_sum = c[12]; out->tiles_traced = c[13]; out->tile_rounds_max = c[14]; out->cycles_test = c[15]; out->tests_executed = c[16];
     out->runs_streamed = c[17]; out->run_ray_trips = c[18]; out->cycles_cull = c[19];
+    out->wave_cycles_max = c[21]; out->span_cycles = (c[23] > c[22]) ? c[23] - c[22] : 0;
     return RT_OK;
 }
 

@@ -672,7 +672,7 @@ __device__ __forceinline__ void dda_setup(Dda& w, const GridU& g, float ox, floa
 // One step of the walk loop, Serial/grid.h:216-227, plus the early-exit rule. Returns false when the ray is done.
 // stepAxis comes from the 3-bit compare table {2,1,2,1,2,2,0,0}: axis 0 iff next0 < next1 and next0 < next2,
 // axis 1 iff not (next0 < next1) and next1 < next2, else axis 2. Written without branches on the axis.
-__device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t, float slack) {
+__device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t, float slack, float* crossed_t = nullptr) {
     // Copies that the optimiser has to treat as register values: without them it rewrites the selects below as one
     // load from a selected address, which pins the whole state in scratch memory.
     float n0 = w.next0, n1 = w.next1, n2 = w.next2, d0 = w.delta0, d1 = w.delta1, d2 = w.delta2;
@@ -692,6 +692,7 @@ __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t
     if (lf == 0) return false;                      // Pos[stepAxis] == Out[stepAxis]
     const float dl = is0 ? d0 : (is1 ? d1 : d2);
     const int cs = is0 ? c0 : (is1 ? c1 : c2);
+    if (crossed_t) *crossed_t = nx_t;
     const float nn = nx_t + dl;
     w.next0 = is0 ? nn : n0;
     w.next1 = is1 ? nn : n1;
@@ -719,22 +720,60 @@ __device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* 
     __syncthreads();
 }
 
-// COST ESTIMATE per listed tile: the ray of the tile's centre pixel is walked through the whole grid (no triangle
-// tests) and the triangle counts of the occupied voxels it visits are summed. Tiles whose rays graze the surface or
-// cross crowded voxels get a large estimate; they are queued first and cut into smaller work units (k_bucket), so the
-// longest-running units start early and the frame does not end on a single wavefront.
-// work[] words: [0] listed tiles, [1] dequeue head, [2..4] tiles per cost class (0 = most expensive).
+// COST ESTIMATE per listed tile, from the ray of the tile's centre pixel alone and without any triangle test: the ray
+// is walked through the whole grid and the occupied voxels it meets and their triangle counts are summed; a stand-in
+// shadow ray, started where the primary ray enters its first occupied voxel, is walked the same way. The estimate is a
+// weighted sum of the four numbers. Tiles whose rays graze the surface or cross crowded voxels get a large estimate;
+// they are queued first and cut into smaller work units (k_bucket), so the longest-running units start early and the
+// frame does not end on a single wavefront.
+// work[] words: [0] listed tiles, [1] dequeue head; tiles per queue list from RT_WORK_LIST_COUNTS on, in another cache
+// line than the dequeue head: every dequeue reads them, and loads from the line all wavefronts hit with atomics queue up.
 #define RT_EST_CELLS 28          // occupied voxels noted per estimate ray (LDS: 4 bytes x 256 lanes each)
-__global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, RtFrame f, const uint32_t* work, const uint32_t* tile_list,
-                                                  uint32_t* cost, unsigned long long* cost_sum) {
+
+// Walks one ray through the grid. The walk itself only touches LDS: the occupied voxels are noted in a per-lane list
+// (the first RT_EST_CELLS of them) and their triangle counts are then fetched with independent loads, several in
+// flight, instead of one dependent memory round trip per voxel; longer walks are scaled up.
+__device__ __forceinline__ void estimate_walk(const RtSceneDev& s, const GridU& g, const uint32_t* bitmap, uint32_t* cells, float ox, float oy,
+                                              float oz, float dx, float dy, float dz, float mint, uint32_t& tris, uint32_t& voxels, float& t_first) {
+    tris = 0; voxels = 0; t_first = -1.f;
+    float rayT;
+    if (!grid_entry(g, ox, oy, oz, dx, dy, dz, mint, rayT)) return;
+    Dda w;
+    dda_setup(w, g, ox, oy, oz, dx, dy, dz, rayT);
+    bool alive = true;
+    float t_in = rayT;
+    uint32_t met = 0;
+    while (alive) {
+        if ((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u) {
+            if (met == 0) t_first = t_in;
+            if (met < RT_EST_CELLS) cells[met * 256 + threadIdx.x] = (uint32_t)w.cell;
+            ++met;
+        }
+        alive = dda_advance(w, false, 0.f, 0.f, &t_in);
+    }
+    const uint32_t kept = met < RT_EST_CELLS ? met : RT_EST_CELLS;
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < kept; k += 4) {
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t cell = cells[((k + j < kept) ? k + j : k) * 256 + threadIdx.x];
+            lo[j] = s.cell_start[cell]; hi[j] = s.cell_start[cell + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (k + j < kept) c += hi[j] - lo[j];
+    }
+    if (met > kept) c = (uint32_t)((unsigned long long)c * met / kept);
+    tris = c; voxels = met;
+}
+
+__global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, const uint32_t* work, const uint32_t* tile_list,
+                                                  uint32_t* cost, unsigned long long* cost_sum, uint32_t* feat_by_tile, uint32_t n_tiles, float4 wgt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
     const uint32_t n = work[0];
     if (blockIdx.x * blockDim.x >= n) return;
     bitmap_to_lds(bitmap, s.occupancy, (s.grid->n_cells + 31) >> 5);
-    // The walk itself only touches LDS: the occupied voxels a ray meets are noted in a per-lane list (the first
-    // RT_EST_CELLS of them), and their triangle counts are then fetched with independent loads, several in flight,
-    // instead of one dependent memory round trip per voxel.
     uint32_t* cells = bitmap + ((s.grid->n_cells + 31) >> 5);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t c = 0;
@@ -744,34 +783,24 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
         tile_pixel(f, tile, 27, x, y_local, y);                     // pixel (3,3) of the tile
         if (x >= f.width || y >= f.height) tile_pixel(f, tile, 0, x, y_local, y);
         const GridU g = load_grid(s.grid);
-        float dx, dy, dz, rayT;
+        float dx, dy, dz;
         primary_ray(cam, f, x, y, dx, dy, dz);
-        uint32_t met = 0;
-        if (grid_entry(g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, rayT)) {
-            Dda w;
-            dda_setup(w, g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, rayT);
-            bool alive = true;
-            while (alive) {
-                if ((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u) {
-                    if (met < RT_EST_CELLS) cells[met * 256 + threadIdx.x] = (uint32_t)w.cell;
-                    ++met;
-                }
-                alive = dda_advance(w, false, 0.f, 0.f);
-            }
+        uint32_t tp, vp, ts = 0, vs = 0;
+        float t_first, unused;
+        estimate_walk(s, g, bitmap, cells, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, tp, vp, t_first);
+        if (t_first >= 0.f) {
+            const float px = cam.pos[0] + dx * t_first, py = cam.pos[1] + dy * t_first, pz = cam.pos[2] + dz * t_first;
+            float sx = px - sh.light[0], sy = py - sh.light[1], sz = pz - sh.light[2];
+            normalize3(sx, sy, sz);
+            estimate_walk(s, g, bitmap, cells, px, py, pz, sx, sy, sz, sh.eps, ts, vs, unused);
         }
-        const uint32_t kept = met < RT_EST_CELLS ? met : RT_EST_CELLS;
-        for (uint32_t k = 0; k < kept; k += 4) {
-            uint32_t lo[4], hi[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t cell = cells[((k + j < kept) ? k + j : k) * 256 + threadIdx.x];
-                lo[j] = s.cell_start[cell]; hi[j] = s.cell_start[cell + 1];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (k + j < kept) c += hi[j] - lo[j];
-        }
-        if (met > kept) c = (uint32_t)((unsigned long long)c * met / kept);     // longer walks: scaled up
+        const float e = wgt.x * (float)tp + wgt.y * (float)vp + wgt.z * (float)ts + wgt.w * (float)vs;
+        c = e < 4.0e9f ? (uint32_t)e : 4000000000u;
         cost[i] = c;
+        if (feat_by_tile) {
+            feat_by_tile[tile] = tp; feat_by_tile[n_tiles + tile] = vp;
+            feat_by_tile[2 * n_tiles + tile] = ts; feat_by_tile[3 * n_tiles + tile] = vs;
+        }
     }
     unsigned long long t = c;
 #pragma unroll
@@ -779,35 +808,47 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
     if ((threadIdx.x & 63) == 0 && t) atomicAdd(cost_sum, t);
 }
 
+// QUEUE ORDER. The listed tiles are spread over RT_QUEUE_LISTS lists that the trace kernel serves one after the other:
+//   lists 0..7   expensive tiles (estimate >= lim0 = 1/div0 of the even share of one wavefront), most expensive first,
+//                one list per factor sqrt(2);
+//   lists 8..11  cheap tiles (below lim1 = share/div1), one list per factor 2;
+//   lists 12..15 the tiles in between, one list per quarter of the log range, served last: they are cut into small units
+//                and level out what the estimates got wrong.
+// Every list has its own unit size (RtFrame::unit_shifts).
 __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* tile_list, const uint32_t* cost,
-                                                const unsigned long long* cost_sum, uint32_t* list0, uint32_t* list1, uint32_t* list2,
+                                                const unsigned long long* cost_sum, uint32_t* lists, uint32_t cap,
                                                 float div0, float div1, int n_waves) {
     const uint32_t n = work[0];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if (blockIdx.x * blockDim.x >= n) return;
-    // class limits: a tile is "expensive" when its estimate exceeds 1/div0 of the work one wavefront would get if the
-    // frame were spread evenly over the n_waves persistent wavefronts, "medium" above 1/div1 of it
     const float share = (float)((double)*cost_sum / (double)n_waves);
-    const float lim0 = share / div0, lim1 = share / div1;
+    const float lim0 = fmaxf(share / div0, 1.f), lim1 = fmaxf(share / div1, 0.5f);
     int cls = -1;
     uint32_t tile = 0;
     if (i < n) {
         tile = tile_list[i];
-        const float c = (float)cost[i];
-        cls = (c > lim0) ? 0 : ((c > lim1) ? 1 : 2);
+        const float c = fmaxf((float)cost[i], 0.25f);
+        if (c >= lim0) {
+            const int h = (int)(2.f * __log2f(c / lim0));
+            cls = 7 - (h < 0 ? 0 : (h > 7 ? 7 : h));
+        } else if (c >= lim1) {
+            const int q = (int)(4.f * __log2f(c / lim1) / fmaxf(__log2f(lim0 / lim1), 1e-3f));
+            cls = 12 + (3 - (q < 0 ? 0 : (q > 3 ? 3 : q)));
+        } else {
+            const int q = (int)__log2f(lim1 / c);
+            cls = 8 + (q < 0 ? 0 : (q > 3 ? 3 : q));
+        }
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t* lists[3] = {list0, list1, list2};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < RT_QUEUE_LISTS; ++k) {
         const unsigned long long m = __ballot(cls == k);
         if (!m) continue;
         uint32_t base = 0;
         const int first = __ffsll((long long)m) - 1;
-        if (lane == first) base = atomicAdd(&work[2 + k], (uint32_t)__popcll(m));
+        if (lane == first) base = atomicAdd(&work[RT_WORK_LIST_COUNTS + k], (uint32_t)__popcll(m));
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-        if (cls == k) lists[k][base + (uint32_t)__popcll(m & lt_mask)] = tile;
+        if (cls == k) lists[(size_t)k * cap + base + (uint32_t)__popcll(m & lt_mask)] = tile;
     }
 }
 
@@ -1044,7 +1085,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
                     lm &= lm - 1;
-                    const double rdx = bcast_f64(ddx, i), rdy = bcast_f64(ddy, i), rdz = bcast_f64(ddz, i);
+                    const double rdx = (double)bcast_f32(dx, i), rdy = (double)bcast_f32(dy, i), rdz = (double)bcast_f32(dz, i);   // widening is exact
                     if (!SHARED_ORIGIN) {
                         const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
                         sx = t.v0x - rox; sy = t.v0y - roy; sz = t.v0z - roz;
@@ -1126,6 +1167,10 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
     return hit;
 }
 
+// pow() for exponents other than the reference's 4. Kept out of line: inlined, its two dozen polynomial constants are
+// hoisted into registers for the whole persistent loop of the trace kernel.
+__device__ __attribute__((noinline)) double pow_general(double x, double a) { return pow(x, a); }
+
 struct RtTraceArgs {
     RtSceneDev s;
     RtCamera cam;
@@ -1133,11 +1178,12 @@ struct RtTraceArgs {
     RtFrame f;
     RtOutputs o;
     uint32_t* work;
-    const uint32_t* lists[3];     // tiles per cost class, most expensive first
+    const uint32_t* lists;        // RT_QUEUE_LISTS tile lists of list_cap entries each, in queue order
+    uint32_t list_cap;
 };
 
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArgs args_in_kernarg_segment) {
+__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArgs args_in_kernarg_segment) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
@@ -1159,13 +1205,10 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
     // Work unit of a wavefront: a 2^-k part of an 8x8 tile (64, 32, 16 or 8 rays, Z-order blocks). The tiles come in three
     // cost classes (k_bucket), most expensive first, and the expensive classes are cut finer, so that the long-running
     // units start early and are spread over many wavefronts while the bulk of the frame runs as large, efficient units.
-    // queue order: q0, q1, q2 name the cost class served first, second and third
-    const int q0 = (A->f.unit_shifts >> 12) & 3, q1 = (A->f.unit_shifts >> 14) & 3, q2 = (A->f.unit_shifts >> 16) & 3;
-    const int us0 = (A->f.unit_shifts >> (8 - 4 * q0)) & 15, us1 = (A->f.unit_shifts >> (8 - 4 * q1)) & 15, us2 = (A->f.unit_shifts >> (8 - 4 * q2)) & 15;
-    const uint32_t u_end0 = work[2 + q0] << us0, u_end1 = u_end0 + (work[2 + q1] << us1), n_units = u_end1 + (work[2 + q2] << us2);
     // frame counters are summed per wavefront and added to memory once, after the last unit
     uint32_t acc_hits = 0, acc_shadowed = 0;
     unsigned long long acc_ray[6] = {0, 0, 0, 0, 0, 0}, acc_w[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_cyc = 0, max_rounds = 0;
+    const long long wave_t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
     uint32_t slot_next = 0;
     for (;;) {
         asm volatile("" ::: "memory");
@@ -1174,13 +1217,24 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
         const RtShade& sh = A->sh;
         const RtFrame& f = A->f;
         const RtOutputs& o = A->o;
+        // units per list (lane k < 16 looks after list k), requested before the atomic so that both round trips overlap
+        const uint32_t my_shift = (lane < RT_QUEUE_LISTS) ? (uint32_t)((f.unit_shifts >> (4 * lane)) & 15ull) : 0u;
+        const uint32_t my_units = (lane < RT_QUEUE_LISTS) ? (work[RT_WORK_LIST_COUNTS + lane] << my_shift) : 0u;
         if (lane == 0) slot_next = atomicAdd(&work[1], 1u);
         const uint32_t slot = __builtin_amdgcn_readfirstlane(slot_next);
-        if (slot >= n_units) break;
-        int ushift, tile, sub;
-        if (slot < u_end0) { ushift = us0; tile = (int)A->lists[q0][slot >> us0]; sub = (int)(slot & ((1u << us0) - 1u)); }
-        else if (slot < u_end1) { const uint32_t r = slot - u_end0; ushift = us1; tile = (int)A->lists[q1][r >> us1]; sub = (int)(r & ((1u << us1) - 1u)); }
-        else { const uint32_t r = slot - u_end1; ushift = us2; tile = (int)A->lists[q2][r >> us2]; sub = (int)(r & ((1u << us2) - 1u)); }
+        uint32_t my_end = my_units;
+#pragma unroll
+        for (int off = 1; off < RT_QUEUE_LISTS; off <<= 1) {
+            const uint32_t v = __shfl_up(my_end, off);
+            if (lane >= off) my_end += v;
+        }
+        const unsigned long long owner = __ballot(lane < RT_QUEUE_LISTS && slot < my_end);
+        if (!owner) break;                                  // the queue is empty
+        const int li = __ffsll((long long)owner) - 1;
+        const int ushift = __builtin_amdgcn_readlane((int)my_shift, li);
+        const uint32_t rel = slot - (uint32_t)__builtin_amdgcn_readlane((int)(my_end - my_units), li);
+        const int tile = (int)A->lists[(size_t)li * A->list_cap + (rel >> ushift)];
+        const int sub = (int)(rel & ((1u << ushift) - 1u));
         // lane -> pixel of the tile: the tile's 64 pixels are numbered along a Z-order curve and unit `sub` owns
         // 64 >> ushift consecutive ones (a compact 8x8, 8x4, 4x4, 4x2 ... block); the other lanes carry no ray
         const int per_unit = 64 >> ushift;
@@ -1230,7 +1284,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
             const double xs = (double)max_std(0.f, ndh);
             double pw;
             if (sh.spec_alpha == 4.0f) { const double x2 = xs * xs; pw = x2 * x2; }
-            else pw = pow(xs, (double)sh.spec_alpha);
+            else pw = pow_general(xs, (double)sh.spec_alpha);
             const float fs = (float)((double)sh.ks * pw);
             cr = (colr * fs) * sh.light_intensity + (colr * fd) * sh.light_intensity;
             cg = (colg * fs) * sh.light_intensity + (colg * fd) * sh.light_intensity;
@@ -1259,7 +1313,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
                 acc_w[9] += wp.cyc_cull + ws.cyc_cull;
                 if (cyc > max_cyc) max_cyc = cyc;
                 if (wp.rounds + ws.rounds > max_rounds) max_rounds = wp.rounds + ws.rounds;
-                if (lane == 0 && o.unit_cost) o.unit_cost[slot] = (uint32_t)cyc;
+                if (lane == 0 && o.unit_cost) { o.unit_cost[slot] = (uint32_t)cyc; atomicAdd(&o.tile_cycles[tile], (uint32_t)cyc); }
             }
         }
         if (in_unit) write_pixel(f, o, x, y_local, cr, cg, cb, id);
@@ -1291,6 +1345,9 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 3) k_trace(RtTraceArg
                 atomicAdd(&counters[17], acc_w[7]);
                 atomicAdd(&counters[18], acc_w[8]);
                 atomicAdd(&counters[19], acc_w[9]);
+                atomicMax(&counters[21], acc_w[4]);                                           // busiest wavefront
+                atomicMin(&counters[22], (unsigned long long)wave_t0);                         // first start
+                atomicMax(&counters[23], (unsigned long long)__builtin_amdgcn_s_memtime());    // last end
             }
         }
     }
@@ -1307,13 +1364,14 @@ static int trace_blocks(const RtFrame& f, const RtRenderWork& wk) {
 
 // Work list of a frame: tiles that see the grid, their cost estimates and cost classes. Needs the grid's cell_start and
 // occupancy, not the triangle records, so it can run beside the second half of a grid build.
-hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtFrame f, RtRenderWork wk, hipStream_t st) {
+hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtRenderWork wk, hipStream_t st) {
     const int n_cls = wk.ntx * wk.ntb;
     if (n_cls <= 0 || s.n_tris == 0) return hipSuccess;
     k_classify<<<(n_cls + 4 * RT_CLS_TILES_PER_WAVE - 1) / (4 * RT_CLS_TILES_PER_WAVE), 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
     const int nb = (n_cls + 255) / 256;
-    k_estimate<<<nb, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum);
-    k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.list[0], wk.list[1], wk.list[2], wk.thr0, wk.thr1, trace_blocks(f, wk) * RT_WAVES_PER_BLOCK);
+    k_estimate<<<nb, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles,
+                                                                                        make_float4(wk.est_w[0], wk.est_w[1], wk.est_w[2], wk.est_w[3]));
+    k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.lists, wk.list_cap, wk.thr0, wk.thr1, trace_blocks(f, wk) * RT_WAVES_PER_BLOCK);
     return hipGetLastError();
 }
 
@@ -1323,7 +1381,7 @@ hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, Rt
     const size_t lds = rt_trace_lds_bytes(wk.bitmap_words);
     RtTraceArgs ta;
     ta.s = s; ta.cam = cam; ta.sh = sh; ta.f = f; ta.o = o; ta.work = wk.work;
-    ta.lists[0] = wk.list[0]; ta.lists[1] = wk.list[1]; ta.lists[2] = wk.list[2];
+    ta.lists = wk.lists; ta.list_cap = wk.list_cap;
     if (f.count_work) k_trace<true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     else k_trace<false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     return hipGetLastError();

@@ -1,5 +1,6 @@
 """Scheduling diagnostics of the trace kernel for one workload (GPU)."""
 import importlib, sys, os
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench
 rt = importlib.import_module("ray-tracer_amd")
@@ -16,8 +17,30 @@ for w in sys.argv[1:]:
           "tile cycles avg", int(st["tile_cycles_sum"] / t), "max", st["tile_cycles_max"],
           "tests", st["tests_primary"] + st["tests_shadow"], "executed", st["tests_executed"], "steps", st["steps_primary"] + st["steps_shadow"],
           "| runs", st["runs_streamed"], "trips", st["run_ray_trips"], "cyc cull/tile", int(st["cycles_cull"] / t))
-    import numpy as np
-    c = scene.unit_costs(((W + 7) // 8) * ((H + 7) // 8) * 64)
+    print("   kernel span", st["span_cycles"], "busiest wave", st["wave_cycles_max"], "mean wave (3072)", int(st["tile_cycles_sum"] / 3072))
+    nt = ((W + 7) // 8) * ((H + 7) // 8)
+    c = scene.unit_costs(nt * 64)
+    feat = c[16 * nt:20 * nt].astype(np.float64).reshape(4, nt); act = c[20 * nt:21 * nt].astype(np.float64)
+    c = c[:16 * nt]
+    m = act > 0
+    if m.sum() > 10:
+        F, a = feat[:, m], act[m]
+        for k, nm in enumerate(["primary tris", "primary voxels", "shadow tris", "shadow voxels"]):
+            print("   corr(%s, measured) = %.3f" % (nm, np.corrcoef(F[k], a)[0, 1]))
+        X = np.vstack([F, np.ones(len(a))]).T
+        wts, *_ = np.linalg.lstsq(X, a, rcond=None)
+        pred = X @ wts
+        print("   least squares weights", np.round(wts, 1), "corr(fit, measured) = %.3f" % np.corrcoef(pred, a)[0, 1])
+        np.save("gpurun_out/diag_%s_feat.npy" % w, feat); np.save("gpurun_out/diag_%s_act.npy" % w, act)
+    q = c[:st["tiles_traced"]].astype(np.float64)        # unit costs in queue order
+    import heapq
+    def makespan(costs, nw=3072):
+        h = [0.0] * nw
+        for x in costs:
+            heapq.heapreplace(h, h[0] + x)
+        return max(h)
+    print("   simulated greedy makespan: queue order %.0f | sorted descending %.0f | mean load %.0f | max unit %.0f" % (
+        makespan(q), makespan(np.sort(q)[::-1]), q.sum() / 3072, q.max()))
     c = c[c > 0].astype(np.float64)
     if len(c):
         c.sort()
