@@ -151,33 +151,48 @@ __device__ __forceinline__ void tri_voxel_range(const RtBuildDev& b, const RtGri
     }
 }
 
-// COUNT: one thread per triangle. Most triangles lie in a single voxel and neighbouring triangle indices
-// tend to share it, so the lanes of a wavefront that hit the same voxel are counted with one atomic;
-// triangles that span several voxels add one atomic per voxel.
+// Groups of lanes that name the same voxel `c`: head = first lane of my group, rank = my place in it, size = its lanes.
+// The first RT_GROUP_TRIPS distinct voxels of the wavefront are grouped exactly (one trip each); with coherent meshes
+// that covers the wavefront. Lanes left over when every lane names another voxel (large triangles) stay on their own.
+#define RT_GROUP_TRIPS 8
+__device__ __forceinline__ void lane_groups(bool act, int c, int lane, int& head, uint32_t& rank, uint32_t& size) {
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    head = lane; rank = 0; size = 1;
+    unsigned long long rem = __ballot(act);
+    for (int trip = 0; trip < RT_GROUP_TRIPS && rem; ++trip) {
+        const int l = __ffsll((long long)rem) - 1;
+        const int c0 = __builtin_amdgcn_readlane(c, l);
+        const bool mine = act && c == c0;
+        const unsigned long long m = __ballot(mine);
+        if (mine) { head = l; rank = (uint32_t)__popcll(m & lt_mask); size = (uint32_t)__popcll(m); }
+        rem &= ~m;
+    }
+}
+
+// COUNT: one thread per triangle. Atomics are the expensive part (they are carried out at the memory side), so the lanes
+// of a wavefront pool them: in round r every triangle names the r-th voxel of its range, lanes naming the same voxel
+// form a group (lane_groups), and one lane adds the group's size. Neighbouring triangle indices tend to share voxels, also the ones
+// straddling a voxel border, so a wavefront issues a few atomics per round instead of one per reference.
 __global__ void __launch_bounds__(256) k_count(RtBuildDev b) {
-    __shared__ RtGrid g;
-    if (threadIdx.x == 0) g = *b.grid;
-    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool valid = i < b.n_tris;
     int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
+    const RtGrid g = *b.grid;                  // same address in every lane; in flight together with the vertex loads
     if (valid) tri_voxel_range(b, g, i, vmin, vmax);
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
-    const bool single = valid && vmin[0] == vmax[0] && vmin[1] == vmax[1] && vmin[2] == vmax[2];
-    const int c = vmin[2] * nxy + vmin[1] * nx + vmin[0];
-    unsigned long long rem = __ballot(single);
-    while (rem) {
-        const int l = __ffsll((long long)rem) - 1;
-        const int c0 = __builtin_amdgcn_readlane(c, l);
-        const unsigned long long m = __ballot(single && c == c0);
-        if (lane == l) atomicAdd(&b.cell_count[c0], (uint32_t)__popcll(m));
-        rem &= ~m;
+    const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
+    const int n = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
+    int x = 0, y = 0, z = 0;
+    for (int r = 0;; ++r) {
+        const bool act = r < n;
+        if (!__ballot(act)) break;
+        const int c = (vmin[2] + z) * nxy + (vmin[1] + y) * nx + (vmin[0] + x);
+        if (++x == ex) { x = 0; if (++y == ey) { y = 0; ++z; } }
+        int head; uint32_t rank, size;
+        lane_groups(act, c, lane, head, rank, size);
+        if (act && lane == head) atomicAdd(&b.cell_count[c], size);
     }
-    if (valid && !single)
-        for (int z = vmin[2]; z <= vmax[2]; ++z)
-            for (int y = vmin[1]; y <= vmax[1]; ++y)
-                for (int x = vmin[0]; x <= vmax[0]; ++x) atomicAdd(&b.cell_count[z * nxy + y * nx + x], 1u);
 }
 
 // SCAN part 1: per-chunk totals. A chunk is RT_SCAN_CHUNK consecutive cells, one 256-thread block each.
@@ -247,48 +262,40 @@ __global__ void k_scan_apply(RtBuildDev b) {
     }
 }
 
-// SCATTER: claims slots in the voxel's segment by counting cell_count back down to zero, with the same
-// per-wavefront aggregation as COUNT. The order inside a voxel is whatever the atomics produce; k_order_emit
-// restores ascending triangle index afterwards.
+// SCATTER: claims slots in the voxel's segment by counting cell_count back down to zero, with the same per-wavefront
+// pooling as COUNT: per round the groups are found first (no memory traffic), then every group's first lane claims the
+// group's slots with ONE atomic, all groups at once, so the wavefront waits for a single round trip per round. The
+// order inside a voxel is whatever the atomics produce; k_row_sort and k_order_emit restore ascending triangle index.
 __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
-    __shared__ RtGrid g;
-    if (threadIdx.x == 0) g = *b.grid;
-    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const RtGrid g = *b.grid;
     if (g.n_refs > b.ref_cap) { if (i == 0) b.grid->overflow = 1; return; }
     const bool valid = i < b.n_tris;
     int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
     if (valid) tri_voxel_range(b, g, i, vmin, vmax);
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
-    const bool single = valid && vmin[0] == vmax[0] && vmin[1] == vmax[1] && vmin[2] == vmax[2];
-    const int c = vmin[2] * nxy + vmin[1] * nx + vmin[0];
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned long long rem = __ballot(single);
-    while (rem) {
-        const int l = __ffsll((long long)rem) - 1;
-        const int c0 = __builtin_amdgcn_readlane(c, l);
-        const bool mine = single && c == c0;
-        const unsigned long long m = __ballot(mine);
+    const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
+    const int n = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
+    int x = 0, y = 0, z = 0;
+    for (int r = 0;; ++r) {
+        const bool act = r < n;
+        if (!__ballot(act)) break;
+        const int c = (vmin[2] + z) * nxy + (vmin[1] + y) * nx + (vmin[0] + x);
+        if (++x == ex) { x = 0; if (++y == ey) { y = 0; ++z; } }
+        uint32_t start = 0;
+        if (act) start = b.cell_start[c];
+        int leader; uint32_t rank, group;
+        lane_groups(act, c, lane, leader, rank, group);
         uint32_t old = 0;
-        if (lane == l) old = atomicSub(&b.cell_count[c0], (uint32_t)__popcll(m));
-        old = (uint32_t)__builtin_amdgcn_readlane((int)old, l);
-        if (mine) {
-            const uint32_t pos = b.cell_start[c0] + old - 1u - (uint32_t)__popcll(m & lt_mask);
+        if (act && lane == leader) old = atomicSub(&b.cell_count[c], group);
+        old = (uint32_t)__shfl((int)old, leader);
+        if (act) {
+            const uint32_t pos = start + old - 1u - rank;
             b.ref_tri[pos] = i;
-            b.ref_cell[pos] = (uint32_t)c0;
+            b.ref_cell[pos] = (uint32_t)c;
         }
-        rem &= ~m;
     }
-    if (valid && !single)
-        for (int z = vmin[2]; z <= vmax[2]; ++z)
-            for (int y = vmin[1]; y <= vmax[1]; ++y)
-                for (int x = vmin[0]; x <= vmax[0]; ++x) {
-                    const uint32_t cc = z * nxy + y * nx + x;
-                    const uint32_t slot = atomicSub(&b.cell_count[cc], 1u) - 1u;
-                    b.ref_tri[b.cell_start[cc] + slot] = i;
-                    b.ref_cell[b.cell_start[cc] + slot] = cc;
-                }
 }
 
 // Record of one (voxel, triangle) reference: {v0.xyz, id}, {v0-v1, lo32(m)}, {v0-v2, hi32(m)} with m the double
@@ -420,11 +427,15 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
         const uint32_t p = blk * 64u + lane;
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         if (p < n_refs) {
-            const uint32_t id = __float_as_uint(b.recs[3ull * p].w);
-            const float4 q0 = b.v0[id], q1 = b.v1[id], q2 = b.v2[id];
-            lo[0] = fminf(q0.x, fminf(q1.x, q2.x)); hi[0] = fmaxf(q0.x, fmaxf(q1.x, q2.x));
-            lo[1] = fminf(q0.y, fminf(q1.y, q2.y)); hi[1] = fmaxf(q0.y, fmaxf(q1.y, q2.y));
-            lo[2] = fminf(q0.z, fminf(q1.z, q2.z)); hi[2] = fmaxf(q0.z, fmaxf(q1.z, q2.z));
+            // the vertices as the record gives them: v0, v0 - e1, v0 - e2. Rebuilding v1 and v2 from the rounded edge
+            // vectors is off by at most one unit in the last place of the larger operand, two orders of magnitude below
+            // the margin the box test adds.
+            const float4 r0 = b.recs[3ull * p], r1 = b.recs[3ull * p + 1], r2 = b.recs[3ull * p + 2];
+            const float q1x = r0.x - r1.x, q1y = r0.y - r1.y, q1z = r0.z - r1.z;
+            const float q2x = r0.x - r2.x, q2y = r0.y - r2.y, q2z = r0.z - r2.z;
+            lo[0] = fminf(r0.x, fminf(q1x, q2x)); hi[0] = fmaxf(r0.x, fmaxf(q1x, q2x));
+            lo[1] = fminf(r0.y, fminf(q1y, q2y)); hi[1] = fmaxf(r0.y, fmaxf(q1y, q2y));
+            lo[2] = fminf(r0.z, fminf(q1z, q2z)); hi[2] = fmaxf(r0.z, fmaxf(q1z, q2z));
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {

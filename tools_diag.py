@@ -17,7 +17,7 @@ for w in sys.argv[1:]:
           "tile cycles avg", int(st["tile_cycles_sum"] / t), "max", st["tile_cycles_max"],
           "tests", st["tests_primary"] + st["tests_shadow"], "executed", st["tests_executed"], "steps", st["steps_primary"] + st["steps_shadow"],
           "| runs", st["runs_streamed"], "trips", st["run_ray_trips"], "cyc cull/tile", int(st["cycles_cull"] / t))
-    print("   kernel span", st["span_cycles"], "busiest wave", st["wave_cycles_max"], "mean wave (3072)", int(st["tile_cycles_sum"] / 3072))
+    print("   kernel span", st["span_cycles"], "busiest wave", st["wave_cycles_max"], "mean wave (4096)", int(st["tile_cycles_sum"] / 4096))
     nt = ((W + 7) // 8) * ((H + 7) // 8)
     c = scene.unit_costs(nt * 64)
     feat = c[16 * nt:20 * nt].astype(np.float64).reshape(4, nt); act = c[20 * nt:21 * nt].astype(np.float64)
@@ -34,13 +34,13 @@ for w in sys.argv[1:]:
         np.save("gpurun_out/diag_%s_feat.npy" % w, feat); np.save("gpurun_out/diag_%s_act.npy" % w, act)
     q = c[:st["tiles_traced"]].astype(np.float64)        # unit costs in queue order
     import heapq
-    def makespan(costs, nw=3072):
+    def makespan(costs, nw=4096):
         h = [0.0] * nw
         for x in costs:
             heapq.heapreplace(h, h[0] + x)
         return max(h)
     print("   simulated greedy makespan: queue order %.0f | sorted descending %.0f | mean load %.0f | max unit %.0f" % (
-        makespan(q), makespan(np.sort(q)[::-1]), q.sum() / 3072, q.max()))
+        makespan(q), makespan(np.sort(q)[::-1]), q.sum() / 4096, q.max()))
     c = c[c > 0].astype(np.float64)
     if len(c):
         c.sort()
