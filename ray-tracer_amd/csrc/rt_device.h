@@ -65,6 +65,7 @@ struct RtOutputs {
     uint8_t* rgb_u8;
     int32_t* hit_id;
     uint32_t* unit_cost;          // counting build only: shader cycles of every work unit, in queue order (may be NULL)
+    uint32_t* unit_info;          // counting build only: tile | unit shift << 24 | queue list << 28 of every work unit (may be NULL)
     uint32_t* tile_cycles;        // counting build only: shader cycles per tile of the frame, summed over its units (may be NULL)
     unsigned long long* counters; // [0] hits, [1] shadowed, [2..4] primary entered/steps/tests, [5..7] shadow entered/steps/tests
 };
@@ -89,6 +90,7 @@ struct RtRenderWork {
 // Build-time scratch.
 struct RtBuildDev {
     float4* v0; float4* v1; float4* v2;
+    float4* tri_rec;              // 3 float4 per triangle: the test record of the triangle (see emit_record), made at upload
     uint32_t n_tris;
     float cube_root;              // 3.f * powf((float)T, 1.f/3.f), evaluated on the host (libm)
     RtGrid* grid;

@@ -64,7 +64,7 @@ struct rt_scene {
     bool grid_valid = false;
     uint32_t known_refs = 0;           // reference count of the current triangle list once measured
     bool refs_known = false;
-    DevBuf<float4> v0, v1, v2;
+    DevBuf<float4> v0, v1, v2, tri_rec;
     DevBuf<float> d_mesh_color;
     DevBuf<RtGrid> d_grid;
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
@@ -116,7 +116,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->device >= 0) {
         (void)hipSetDevice(s->device);
-        s->v0.release(); s->v1.release(); s->v2.release(); s->d_mesh_color.release(); s->d_grid.release();
+        s->v0.release(); s->v1.release(); s->v2.release(); s->tri_rec.release(); s->d_mesh_color.release(); s->d_grid.release();
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
         s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); s->queue_lists.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
@@ -311,7 +311,7 @@ static int scene_bind_device(rt_scene* s) {
 
 static RtBuildDev build_args(rt_scene* s) {
     RtBuildDev b;
-    b.v0 = s->v0.p; b.v1 = s->v1.p; b.v2 = s->v2.p;
+    b.v0 = s->v0.p; b.v1 = s->v1.p; b.v2 = s->v2.p; b.tri_rec = s->tri_rec.p;
     b.n_tris = (uint32_t)s->tri_mesh.size();
     b.cube_root = 3.f * powf((float)s->tri_mesh.size(), 1.f / 3.f);   // Serial/grid.h:94, host libm
     b.grid = s->d_grid.p;
@@ -330,7 +330,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     if (s->uploaded) return RT_OK;
     const size_t T = s->tri_mesh.size();
     const size_t Tn = T ? T : 1;
-    if ((rc = s->v0.ensure(Tn)) || (rc = s->v1.ensure(Tn)) || (rc = s->v2.ensure(Tn))) return rc;
+    if ((rc = s->v0.ensure(Tn)) || (rc = s->v1.ensure(Tn)) || (rc = s->v2.ensure(Tn)) || (rc = s->tri_rec.ensure(3 * Tn))) return rc;
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
@@ -509,7 +509,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;
-    o.unit_cost = nullptr; o.tile_cycles = nullptr;
+    o.unit_cost = nullptr; o.tile_cycles = nullptr; o.unit_info = nullptr;
     // background everywhere first: black, no hit
     const size_t out_px = (size_t)p->width * (size_t)f.out_rows;
     if (o.rgb_f32) HIP_TRY(hipMemsetAsync(o.rgb_f32, 0, out_px * 3 * sizeof(float), side));
@@ -535,8 +535,9 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         if (s->count_work) {
             if ((rc = s->unit_cost.ensure((tiles ? tiles : 1) * 64))) return rc;
             HIP_TRY(hipMemsetAsync(s->unit_cost.p, 0, (tiles ? tiles : 1) * 64 * sizeof(uint32_t), side));
-            // layout: 16 x tiles unit slots, then the four estimate features and the measured cycles of every tile of the frame
-            o.unit_cost = s->unit_cost.p; o.tile_cycles = s->unit_cost.p + 20 * tiles; wk.est_by_tile = s->unit_cost.p + 16 * tiles;
+            // layout: 16 x tiles unit slots, the four estimate features and the measured cycles of every tile of the frame,
+            // then 16 x tiles unit descriptions
+            o.unit_cost = s->unit_cost.p; o.tile_cycles = s->unit_cost.p + 20 * tiles; o.unit_info = s->unit_cost.p + 21 * tiles; wk.est_by_tile = s->unit_cost.p + 16 * tiles;
         }
         wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 24);
         wk.cost_sum = s->counters.p + 20;

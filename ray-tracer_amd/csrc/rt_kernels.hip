@@ -50,19 +50,30 @@ __device__ __forceinline__ float dec_f32(uint32_t u) {
 // ------------------------------------------------------------------------------------------------
 // scene upload: host triangle list (9 floats per triangle) -> three float4 streams in HBM
 // ------------------------------------------------------------------------------------------------
+// Also makes every triangle's test record: {v0.xyz, id}, {v0-v1, lo32(m)}, {v0-v2, hi32(m)} with m the double
+// (e1.y*e2.z - e2.y*e1.z), the one 2x2 minor of Triangle::Intersect (Serial/geometry.h:131-177) that does not depend on
+// the ray. The grid build copies these records into voxel order.
 __global__ void k_upload_convert(const float* __restrict__ tri9, const uint32_t* __restrict__ mesh, float4* v0, float4* v1,
-                                 float4* v2, uint32_t n) {
+                                 float4* v2, float4* tri_rec, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* t = tri9 + 9ull * i;
     v0[i] = make_float4(t[0], t[1], t[2], __uint_as_float(mesh[i]));
     v1[i] = make_float4(t[3], t[4], t[5], 0.f);
     v2[i] = make_float4(t[6], t[7], t[8], 0.f);
+    const float e1x = t[0] - t[3], e1y = t[1] - t[4], e1z = t[2] - t[5];
+    const float e2x = t[0] - t[6], e2y = t[1] - t[7], e2z = t[2] - t[8];
+    const double m = (double)e1y * (double)e2z - (double)e2y * (double)e1z;
+    const unsigned long long mb = (unsigned long long)__double_as_longlong(m);
+    float4* o = tri_rec + 3ull * i;
+    o[0] = make_float4(t[0], t[1], t[2], __uint_as_float(i));
+    o[1] = make_float4(e1x, e1y, e1z, __uint_as_float((uint32_t)mb));
+    o[2] = make_float4(e2x, e2y, e2z, __uint_as_float((uint32_t)(mb >> 32)));
 }
 
 hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh, RtBuildDev b, hipStream_t st) {
     if (b.n_tris == 0) return hipSuccess;
-    k_upload_convert<<<(b.n_tris + 255) / 256, 256, 0, st>>>(d_tri9, d_mesh, b.v0, b.v1, b.v2, b.n_tris);
+    k_upload_convert<<<(b.n_tris + 255) / 256, 256, 0, st>>>(d_tri9, d_mesh, b.v0, b.v1, b.v2, b.tri_rec, b.n_tris);
     return hipGetLastError();
 }
 
@@ -298,18 +309,12 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
     }
 }
 
-// Record of one (voxel, triangle) reference: {v0.xyz, id}, {v0-v1, lo32(m)}, {v0-v2, hi32(m)} with m the double
-// (e1.y*e2.z - e2.y*e1.z), the one 2x2 minor of Triangle::Intersect that does not depend on the ray.
+// Record of one (voxel, triangle) reference: the triangle's test record, copied to its place in the voxel's list.
 __device__ __forceinline__ void emit_record(const RtBuildDev& b, uint32_t tri, uint32_t pos) {
-    const float4 p = b.v0[tri], q = b.v1[tri], s = b.v2[tri];
-    const float e1x = p.x - q.x, e1y = p.y - q.y, e1z = p.z - q.z;
-    const float e2x = p.x - s.x, e2y = p.y - s.y, e2z = p.z - s.z;
-    const double m = (double)e1y * (double)e2z - (double)e2y * (double)e1z;
-    const unsigned long long mb = (unsigned long long)__double_as_longlong(m);
+    const float4* r = b.tri_rec + 3ull * tri;
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2];
     float4* o = b.recs + 3ull * pos;
-    o[0] = make_float4(p.x, p.y, p.z, __uint_as_float(tri));
-    o[1] = make_float4(e1x, e1y, e1z, __uint_as_float((uint32_t)mb));
-    o[2] = make_float4(e2x, e2y, e2z, __uint_as_float((uint32_t)(mb >> 32)));
+    o[0] = r0; o[1] = r1; o[2] = r2;
 }
 
 #define RT_ORDER_LDS_IDS 1024          // triangle indices of one voxel a wavefront holds in LDS at a time (16 rows)
@@ -376,9 +381,15 @@ __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
             if (mem) rank -= b0 - first;
             for (uint32_t tile = first; tile < e0; tile += RT_ORDER_LDS_IDS) {
                 const uint32_t nt = (((e0 - tile) < RT_ORDER_LDS_IDS ? (e0 - tile) : RT_ORDER_LDS_IDS) + 63u) & ~63u;   // whole rows
-                for (uint32_t k = lane; k < nt; k += 64) {
-                    const uint32_t q = tile + k;
-                    ids[k] = (q < b0) ? 0u : ((q < e0) ? b.ref_tri[q] + 1u : 0xffffffffu);
+                for (uint32_t k = lane; k < nt; k += 256) {          // four rows per trip, their loads in flight together
+                    uint32_t v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t q = tile + k + 64u * j;
+                        v[j] = (q >= b0 && q < e0) ? b.ref_tri[q] + 1u : ((q < b0) ? 0u : 0xffffffffu);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + 64u * j < nt) ids[k + 64u * j] = v[j];
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (mem) {
@@ -731,7 +742,7 @@ __device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* 
     __syncthreads();
 }
 
-// COST ESTIMATE per listed tile, from the ray of the tile's centre pixel alone and without any triangle test: the ray
+// COST ESTIMATE per listed tile, from the rays of four of its pixels and without any triangle test: each ray
 // is walked through the whole grid and the occupied voxels it meets and their triangle counts are summed; a stand-in
 // shadow ray, started where the primary ray enters its first occupied voxel, is walked the same way. The estimate is a
 // weighted sum of the four numbers. Tiles whose rays graze the surface or cross crowded voxels get a large estimate;
@@ -783,20 +794,23 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
     const uint32_t n = work[0];
-    if (blockIdx.x * blockDim.x >= n) return;
+    if (blockIdx.x * (blockDim.x >> 2) >= n) return;
     bitmap_to_lds(bitmap, s.occupancy, (s.grid->n_cells + 31) >> 5);
     uint32_t* cells = bitmap + ((s.grid->n_cells + 31) >> 5);
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // four lanes per tile, one sample pixel each: (1,1), (6,1), (1,6), (6,6)
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int smp = threadIdx.x & 3;
     uint32_t c = 0;
+    uint32_t tp = 0, vp = 0, ts = 0, vs = 0;
+    int tile = 0;
     if (i < n) {
-        const int tile = (int)tile_list[i];
+        tile = (int)tile_list[i];
         int x, y_local, y;
-        tile_pixel(f, tile, 27, x, y_local, y);                     // pixel (3,3) of the tile
+        tile_pixel(f, tile, ((smp & 2) ? 48 : 8) + ((smp & 1) ? 6 : 1), x, y_local, y);
         if (x >= f.width || y >= f.height) tile_pixel(f, tile, 0, x, y_local, y);
         const GridU g = load_grid(s.grid);
         float dx, dy, dz;
         primary_ray(cam, f, x, y, dx, dy, dz);
-        uint32_t tp, vp, ts = 0, vs = 0;
         float t_first, unused;
         estimate_walk(s, g, bitmap, cells, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, tp, vp, t_first);
         if (t_first >= 0.f) {
@@ -805,6 +819,11 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
             normalize3(sx, sy, sz);
             estimate_walk(s, g, bitmap, cells, px, py, pz, sx, sy, sz, sh.eps, ts, vs, unused);
         }
+    }
+    // the tile's numbers: sums over its four samples (neighbouring lanes)
+    tp += __shfl_xor(tp, 1); vp += __shfl_xor(vp, 1); ts += __shfl_xor(ts, 1); vs += __shfl_xor(vs, 1);
+    tp += __shfl_xor(tp, 2); vp += __shfl_xor(vp, 2); ts += __shfl_xor(ts, 2); vs += __shfl_xor(vs, 2);
+    if (i < n && smp == 0) {
         const float e = wgt.x * (float)tp + wgt.y * (float)vp + wgt.z * (float)ts + wgt.w * (float)vs;
         c = e < 4.0e9f ? (uint32_t)e : 4000000000u;
         cost[i] = c;
@@ -1324,7 +1343,10 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
                 acc_w[9] += wp.cyc_cull + ws.cyc_cull;
                 if (cyc > max_cyc) max_cyc = cyc;
                 if (wp.rounds + ws.rounds > max_rounds) max_rounds = wp.rounds + ws.rounds;
-                if (lane == 0 && o.unit_cost) { o.unit_cost[slot] = (uint32_t)cyc; atomicAdd(&o.tile_cycles[tile], (uint32_t)cyc); }
+                if (lane == 0 && o.unit_cost) {
+                    o.unit_cost[slot] = (uint32_t)cyc; atomicAdd(&o.tile_cycles[tile], (uint32_t)cyc);
+                    o.unit_info[slot] = (uint32_t)tile | ((uint32_t)ushift << 24) | ((uint32_t)li << 28);
+                }
             }
         }
         if (in_unit) write_pixel(f, o, x, y_local, cr, cg, cb, id);
@@ -1380,7 +1402,7 @@ hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame
     if (n_cls <= 0 || s.n_tris == 0) return hipSuccess;
     k_classify<<<(n_cls + 4 * RT_CLS_TILES_PER_WAVE - 1) / (4 * RT_CLS_TILES_PER_WAVE), 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
     const int nb = (n_cls + 255) / 256;
-    k_estimate<<<nb, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles,
+    k_estimate<<<(n_cls + 63) / 64, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles,
                                                                                         make_float4(wk.est_w[0], wk.est_w[1], wk.est_w[2], wk.est_w[3]));
     k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.lists, wk.list_cap, wk.thr0, wk.thr1, trace_blocks(f, wk) * RT_WAVES_PER_BLOCK);
     return hipGetLastError();

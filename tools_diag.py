@@ -21,6 +21,7 @@ for w in sys.argv[1:]:
     nt = ((W + 7) // 8) * ((H + 7) // 8)
     c = scene.unit_costs(nt * 64)
     feat = c[16 * nt:20 * nt].astype(np.float64).reshape(4, nt); act = c[20 * nt:21 * nt].astype(np.float64)
+    info = c[21 * nt:37 * nt]
     c = c[:16 * nt]
     m = act > 0
     if m.sum() > 10:
@@ -33,6 +34,17 @@ for w in sys.argv[1:]:
         print("   least squares weights", np.round(wts, 1), "corr(fit, measured) = %.3f" % np.corrcoef(pred, a)[0, 1])
         np.save("gpurun_out/diag_%s_feat.npy" % w, feat); np.save("gpurun_out/diag_%s_act.npy" % w, act)
     q = c[:st["tiles_traced"]].astype(np.float64)        # unit costs in queue order
+    qi = info[:st["tiles_traced"]]
+    top = np.argsort(q)[::-1][:12]
+    print("   heaviest units (cycles, slot, list, shift, tile cycles, tile estimate rank):")
+    est_all = 1.0 * feat[0] + 500.0 * feat[1] + 700.0 * feat[3]
+    order = np.argsort(np.argsort(-est_all))
+    for u in top:
+        t_ = int(qi[u] & 0xffffff)
+        print("      %9d slot %6d list %2d shift %d tile %8d rank %d" % (q[u], u, qi[u] >> 28, (qi[u] >> 24) & 15, act[t_], order[t_]))
+    for l in range(16):
+        sel = (qi >> 28) == l
+        if sel.any(): print("      list %2d: units %6d mean %8.0f max %8.0f" % (l, sel.sum(), q[sel].mean(), q[sel].max()))
     import heapq
     def makespan(costs, nw=4096):
         h = [0.0] * nw
