@@ -220,7 +220,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                tinfo = json.load(open(tpath)).get(args.workload)
+                traffic = tinfo["bytes_per_launch"] if tinfo else None
             except Exception:
                 traffic = None
         out = {
@@ -245,8 +246,9 @@ def main():
                 "achieved": round((f32 + f64) / t_render / 1e12, 4), "peak": round((f32 + f64) / t_peak / 1e12, 2), "unit": "TFLOP/s",
                 "frac": round(t_peak / t_render, 5),
                 "traffic": traffic,
+                "traffic_note": "HBM-side bytes of one k_trace launch from the L2 fabric counters (profiles/traffic.json: separate rocprofv3 --pmc passes, FETCH_SIZE doubled on gfx950)",
                 "note": "flops of the triangle tests k_trace executes (%d; the reference's early-exit order needs %d, the rest are skipped by the per-run "
-                        "box test), %d voxel steps and %d rays of rank 0's frame, over the mean k_classify+k_trace time of the timed frames; "
+                        "box test), %d voxel steps and %d rays of rank 0's frame, over the mean k_trace time of the timed frames (hipEvents around the launch, recorded by the library on its stream); "
                         "peak = the same flops at 157.3 TF fp32 + 78.6 TF fp64" % (tests, tests_ref, steps_, nrays),
             },
             "roofline_hbm": {
