@@ -309,14 +309,6 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
     }
 }
 
-// Record of one (voxel, triangle) reference: the triangle's test record, copied to its place in the voxel's list.
-__device__ __forceinline__ void emit_record(const RtBuildDev& b, uint32_t tri, uint32_t pos) {
-    const float4* r = b.tri_rec + 3ull * tri;
-    const float4 r0 = r[0], r1 = r[1], r2 = r[2];
-    float4* o = b.recs + 3ull * pos;
-    o[0] = r0; o[1] = r1; o[2] = r2;
-}
-
 #define RT_ORDER_LDS_IDS 1024          // triangle indices of one voxel a wavefront holds in LDS at a time (16 rows)
 
 // ROW SORT: every aligned row of 64 references is sorted by (voxel, triangle index) inside its wavefront (bitonic
@@ -354,74 +346,115 @@ __global__ void __launch_bounds__(256) k_row_sort(RtBuildDev b) {
 // 7-probe binary search, and a crowded voxel is shared out over as many wavefronts as it has rows.
 // LDS holds index + 1; places of the first row that belong to the previous voxel hold 0 (always counted, and taken
 // off again), places after the voxel's end hold 0xffffffff (never counted).
+// Number of indices below me1 among the sorted rows staged in `ids` (nt entries, whole rows). A row whose last index
+// is below mine counts whole, one whose first index is not below mine counts nothing (two reads of one address for all
+// lanes); only rows that straddle my index are searched. The atomics of k_scatter hand out places almost in index
+// order, so few rows straddle.
+__device__ __forceinline__ uint32_t count_below(const uint32_t* ids, uint32_t nt, uint32_t me1, bool mem) {
+    uint32_t cnt = 0;
+    for (uint32_t r = 0; r < nt; r += 64u) {
+        const uint32_t* s0 = ids + r;
+        const uint32_t first_id = s0[0], last_id = s0[63];
+        const bool whole = last_id < me1, none = !(first_id < me1);
+        if (mem && whole) cnt += 64u;
+        if (__ballot(mem && !whole && !none)) {
+            if (mem && !whole && !none) {
+                uint32_t n0 = 0;
+#pragma unroll
+                for (uint32_t st = 32; st > 0; st >>= 1) n0 += (s0[n0 + st - 1u] < me1) ? st : 0u;
+                n0 += (s0[n0] < me1) ? 1u : 0u;
+                cnt += n0;
+            }
+        }
+    }
+    return cnt;
+}
+
 __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
-    __shared__ __attribute__((aligned(16))) uint32_t ids_all[4][RT_ORDER_LDS_IDS];
+    __shared__ __attribute__((aligned(16))) uint32_t ids_all[4 * RT_ORDER_LDS_IDS];
     const uint32_t n_refs = b.grid->n_refs;
     if (n_refs > b.ref_cap) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t* ids = ids_all[wv];
-    const uint32_t n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + wv;
     const uint32_t n_rows = (n_refs + 63u) / 64u;
-    for (uint32_t row = wave; row < n_rows; row += n_waves) {
-        const uint32_t p = row * 64u + lane;
+    const uint32_t n_quads = (n_rows + 3u) / 4u;            // a block takes four consecutive rows at a time
+    // The inputs of a quad (voxel, index, the voxel's range, first and last voxel of the quad) are fetched one quad ahead:
+    // the kernel is a chain of dependent round trips per quad, and this takes two of them off the chain.
+    struct QuadIn { uint32_t c, me, beg, end, c_first, c_last; };
+    auto fetch = [&](uint32_t quad, QuadIn& q) {
+        q.c = 0xffffffffu; q.me = 0; q.beg = 0; q.end = 0; q.c_first = 0; q.c_last = 1;
+        if (quad >= n_quads) return;
+        const uint32_t p = (quad * 4u + wv) * 64u + lane;
+        if (p < n_refs) { q.c = b.ref_cell[p]; q.me = b.ref_tri[p]; q.beg = b.cell_start[q.c]; q.end = b.cell_start[q.c + 1]; }
+        if (quad * 256u + 255u < n_refs) { q.c_first = b.ref_cell[quad * 256u]; q.c_last = b.ref_cell[quad * 256u + 255u]; }
+    };
+    QuadIn nxt;
+    fetch(blockIdx.x, nxt);
+    for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+        const QuadIn cur = nxt;
+        fetch(quad + gridDim.x, nxt);
+        const uint32_t p = (quad * 4u + wv) * 64u + lane;
         const bool valid = p < n_refs;
-        uint32_t c = 0xffffffffu, me = 0, beg = 0, end = 0;
-        if (valid) { c = b.ref_cell[p]; me = b.ref_tri[p]; beg = b.cell_start[c]; end = b.cell_start[c + 1]; }
+        const uint32_t c = cur.c, me = cur.me, beg = cur.beg, end = cur.end;
         const uint32_t me1 = me + 1u;
         uint32_t rank = 0;
-        unsigned long long rem = __ballot(valid);
-        while (rem) {
-            const int l = __ffsll((long long)rem) - 1;
-            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, l);
-            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)beg, l);
-            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)end, l);
-            const bool mem = valid && c == c0;
-            rem &= ~__ballot(mem);
-            const uint32_t first = b0 & ~63u;
-            if (mem) rank -= b0 - first;
-            for (uint32_t tile = first; tile < e0; tile += RT_ORDER_LDS_IDS) {
-                const uint32_t nt = (((e0 - tile) < RT_ORDER_LDS_IDS ? (e0 - tile) : RT_ORDER_LDS_IDS) + 63u) & ~63u;   // whole rows
-                for (uint32_t k = lane; k < nt; k += 256) {          // four rows per trip, their loads in flight together
+        // the triangle's record is requested now and written once the rank is known
+        float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
+        if (valid) { const float4* r = b.tri_rec + 3ull * me; rec0 = r[0]; rec1 = r[1]; rec2 = r[2]; }
+        // Do all four rows lie in ONE voxel (the usual case inside a crowded voxel)? Then the voxel's index list is staged
+        // once for the whole block instead of once per wavefront. Every wavefront reads the same two words, so the
+        // branch is uniform over the block.
+        const bool shared = cur.c_first == cur.c_last;
+        if (shared) {
+            const uint32_t first = beg & ~63u;              // beg, end are the same in every lane of the block
+            rank -= beg - first;
+            for (uint32_t tile = first; tile < end; tile += 4 * RT_ORDER_LDS_IDS) {
+                const uint32_t nt = (((end - tile) < 4 * RT_ORDER_LDS_IDS ? (end - tile) : 4 * RT_ORDER_LDS_IDS) + 63u) & ~63u;
+                __syncthreads();                            // the previous tile has been read by everyone
+                for (uint32_t k = threadIdx.x; k < nt; k += 1024) {
                     uint32_t v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const uint32_t q = tile + k + 64u * j;
-                        v[j] = (q >= b0 && q < e0) ? b.ref_tri[q] + 1u : ((q < b0) ? 0u : 0xffffffffu);
+                        const uint32_t q = tile + k + 256u * j;
+                        v[j] = (q >= beg && q < end) ? b.ref_tri[q] + 1u : ((q < beg) ? 0u : 0xffffffffu);
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (k + 64u * j < nt) ids[k + 64u * j] = v[j];
+                    for (int j = 0; j < 4; ++j) if (k + 256u * j < nt) ids_all[k + 256u * j] = v[j];
                 }
-                __builtin_amdgcn_wave_barrier();
-                if (mem) {
-                    // four rows per trip: independent probe chains
-                    uint32_t r = 0;
-                    for (; r + 256u <= nt; r += 256u) {
-                        const uint32_t* sr = ids + r;
-                        uint32_t n0 = 0, n1 = 64, n2 = 128, n3 = 192;
+                __syncthreads();
+                rank += count_below(ids_all, nt, me1, true);
+            }
+            __syncthreads();                                // before another quad reuses the tile
+        } else {
+            uint32_t* ids = ids_all + wv * RT_ORDER_LDS_IDS;
+            unsigned long long rem = __ballot(valid);
+            while (rem) {
+                const int l = __ffsll((long long)rem) - 1;
+                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, l);
+                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)beg, l);
+                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)end, l);
+                const bool mem = valid && c == c0;
+                rem &= ~__ballot(mem);
+                const uint32_t first = b0 & ~63u;
+                if (mem) rank -= b0 - first;
+                for (uint32_t tile = first; tile < e0; tile += RT_ORDER_LDS_IDS) {
+                    const uint32_t nt = (((e0 - tile) < RT_ORDER_LDS_IDS ? (e0 - tile) : RT_ORDER_LDS_IDS) + 63u) & ~63u;   // whole rows
+                    for (uint32_t k = lane; k < nt; k += 256) {          // four rows per trip, their loads in flight together
+                        uint32_t v[4];
 #pragma unroll
-                        for (uint32_t st = 32; st > 0; st >>= 1) {
-                            const uint32_t v0 = sr[n0 + st - 1u], v1 = sr[n1 + st - 1u], v2 = sr[n2 + st - 1u], v3 = sr[n3 + st - 1u];
-                            n0 += (v0 < me1) ? st : 0u;
-                            n1 += (v1 < me1) ? st : 0u;
-                            n2 += (v2 < me1) ? st : 0u;
-                            n3 += (v3 < me1) ? st : 0u;
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t q = tile + k + 64u * j;
+                            v[j] = (q >= b0 && q < e0) ? b.ref_tri[q] + 1u : ((q < b0) ? 0u : 0xffffffffu);
                         }
-                        const uint32_t v0 = sr[n0], v1 = sr[n1], v2 = sr[n2], v3 = sr[n3];
-                        rank += (n0 + n1 + n2 + n3 - 384u) + (v0 < me1) + (v1 < me1) + (v2 < me1) + (v3 < me1);
-                    }
-                    for (; r < nt; r += 64u) {
-                        const uint32_t* s0 = ids + r;
-                        uint32_t n0 = 0;
 #pragma unroll
-                        for (uint32_t st = 32; st > 0; st >>= 1) n0 += (s0[n0 + st - 1u] < me1) ? st : 0u;
-                        n0 += (s0[n0] < me1) ? 1u : 0u;
-                        rank += n0;
+                        for (int j = 0; j < 4; ++j) if (k + 64u * j < nt) ids[k + 64u * j] = v[j];
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    rank += count_below(ids, nt, me1, mem);
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
             }
         }
-        if (valid) emit_record(b, me, beg + rank);
+        if (valid) { float4* o = b.recs + 3ull * (beg + rank); o[0] = rec0; o[1] = rec1; o[2] = rec2; }
     }
 }
 

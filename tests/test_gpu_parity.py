@@ -168,3 +168,26 @@ def test_work_counters_match_oracle_early_exit(rt, O, plane10, name):
     for k in ("primary_rays", "primary_entering", "hits", "shadow_entering", "shadowed", "steps_primary", "tests_primary",
               "steps_shadow", "tests_shadow"):
         assert got[k] == want[k], (k, got[k], want[k])
+
+
+@pytest.mark.parametrize("shifts,sched", [
+    ("0000000000000000", None),          # every tile as one 64-ray unit
+    ("4444444444444444", None),          # every tile cut into sixteen 4-ray units
+    ("3210321032103210", None),          # all unit sizes mixed
+    (None, "0.001:0.002"),               # every tile classed expensive
+    (None, "1000:2000"),                 # every tile classed cheap
+])
+def test_unit_sizes_and_cost_classes_do_not_change_the_image(rt, plane10, monkeypatch, shifts, sched):
+    """The work-unit size and the queue order are scheduling only: any setting gives the golden image bit for bit.
+    (The overrides are read when a scene is created.)"""
+    if shifts is not None:
+        monkeypatch.setenv("RT_SHIFTS", shifts)
+    if sched is not None:
+        monkeypatch.setenv("RT_SCHED", sched)
+    for name in ("main_512x512", "main_odd_333x217"):
+        s, W, H, cam = _scene(rt, name, plane10)
+        p = rt.default_params(W, H, **cam_kwargs(cam))
+        rgb, u8, ids = s.render(p, want_u8=True)
+        g_ids, g_rgb = golden(name)
+        check_image(rgb, ids, g_rgb, g_ids)
+        s.close()
