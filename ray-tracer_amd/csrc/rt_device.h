@@ -101,6 +101,7 @@ struct RtBuildDev {
     uint32_t* occupancy;          // RT_MAX_CELLS / 32
     uint32_t* ref_tri;            // ref_cap, unsorted
     uint32_t* ref_cell;           // ref_cap: voxel of each unsorted reference
+    uint2* row_minmax;            // per row of 64 references: smallest and largest triangle index after k_row_sort
     float4* recs;                 // 3 * ref_cap
     float4* blk_bounds;           // 2 * (ref_cap / 64 + 1)
     uint32_t ref_cap;

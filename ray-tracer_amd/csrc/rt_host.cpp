@@ -68,6 +68,7 @@ struct rt_scene {
     DevBuf<float> d_mesh_color;
     DevBuf<RtGrid> d_grid;
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
+    DevBuf<uint2> row_minmax;
     DevBuf<float4> recs, blk_bounds;
     DevBuf<unsigned long long> counters;   // 24 frame counters, then the work-list words (RtRenderWork::work)
     DevBuf<uint32_t> tile_list, unit_cost, tile_cost, queue_lists;
@@ -118,7 +119,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         (void)hipSetDevice(s->device);
         s->v0.release(); s->v1.release(); s->v2.release(); s->tri_rec.release(); s->d_mesh_color.release(); s->d_grid.release();
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
-        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); s->queue_lists.release();
+        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->row_minmax.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); s->queue_lists.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
         for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
         if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -317,7 +318,7 @@ static RtBuildDev build_args(rt_scene* s) {
     b.grid = s->d_grid.p;
     b.bounds_enc = s->bounds_enc.p;
     b.cell_count = s->cell_count.p; b.cell_start = s->cell_start.p; b.block_sums = s->block_sums.p; b.occupancy = s->occupancy.p;
-    b.ref_tri = s->ref_tri.p; b.ref_cell = s->ref_cell.p; b.recs = s->recs.p; b.blk_bounds = s->blk_bounds.p;
+    b.ref_tri = s->ref_tri.p; b.ref_cell = s->ref_cell.p; b.row_minmax = s->row_minmax.p; b.recs = s->recs.p; b.blk_bounds = s->blk_bounds.p;
     b.ref_cap = (uint32_t)s->ref_tri.cap;
     b.counters = s->counters.p;
     return b;
@@ -373,7 +374,7 @@ static int build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_phase1
         s->h_grid = g;
         s->refs_known = true;
         size_t need = g.n_refs ? g.n_refs : 1;
-        if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(2 * (need / 64 + 2)))) return rc;
+        if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)) || (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(2 * (need / 64 + 2)))) return rc;
     } else {
         HIP_TRY(rt_launch_build_phase1(build_args(s), st));
     }

@@ -309,7 +309,6 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
     }
 }
 
-#define RT_ORDER_LDS_IDS 1024          // triangle indices of one voxel a wavefront holds in LDS at a time (16 rows)
 
 // ROW SORT: every aligned row of 64 references is sorted by (voxel, triangle index) inside its wavefront (bitonic
 // network over the lanes). References are already grouped by voxel, so a voxel's references keep their places in the
@@ -335,121 +334,115 @@ __global__ void __launch_bounds__(256) k_row_sort(RtBuildDev b) {
             }
         }
         if (p < n_refs) b.ref_tri[p] = (uint32_t)key;
+        // smallest and largest index of the row: what k_order_emit looks at first for rows that lie inside one voxel
+        const uint32_t first_id = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 0);
+        const uint32_t last_id = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 63);
+        if (lane == 0) b.row_minmax[row] = make_uint2(first_id, last_id);
     }
 }
 
 // ORDER + EMIT: the reference appends triangles to a voxel in ascending index (Serial/grid.h:118-150) and the
 // first-tested triangle wins ties, so every voxel's list is put back into ascending order: each reference finds its
-// rank = the number of smaller indices in its voxel (indices are distinct) and writes its 48-byte record there.
-// A wavefront takes one row of 64 references. For every voxel these belong to, the voxel's index list is streamed
-// through LDS in tiles of whole rows; the rows are sorted (k_row_sort), so the number of smaller indices in a row is a
-// 7-probe binary search, and a crowded voxel is shared out over as many wavefronts as it has rows.
-// LDS holds index + 1; places of the first row that belong to the previous voxel hold 0 (always counted, and taken
-// off again), places after the voxel's end hold 0xffffffff (never counted).
-// Number of indices below me1 among the sorted rows staged in `ids` (nt entries, whole rows). A row whose last index
-// is below mine counts whole, one whose first index is not below mine counts nothing (two reads of one address for all
-// lanes); only rows that straddle my index are searched. The atomics of k_scatter hand out places almost in index
-// order, so few rows straddle.
-__device__ __forceinline__ uint32_t count_below(const uint32_t* ids, uint32_t nt, uint32_t me1, bool mem) {
-    uint32_t cnt = 0;
-    for (uint32_t r = 0; r < nt; r += 64u) {
-        const uint32_t* s0 = ids + r;
-        const uint32_t first_id = s0[0], last_id = s0[63];
-        const bool whole = last_id < me1, none = !(first_id < me1);
-        if (mem && whole) cnt += 64u;
-        if (__ballot(mem && !whole && !none)) {
-            if (mem && !whole && !none) {
-                uint32_t n0 = 0;
+// rank = the number of smaller indices in its voxel (indices are distinct) and its triangle's 48-byte record is copied
+// there. A wavefront takes one row of 64 references. The rows are sorted (k_row_sort), so for a row that lies inside
+// the voxel its smallest and largest index (row_minmax) usually settle the count: a row whose largest index is below
+// mine counts whole, one whose smallest index is not below mine counts nothing. The atomics of k_scatter hand out
+// places almost in index order, so only a few rows straddle an index; those are read (64 indices, one coalesced load),
+// parked in LDS and searched with 7 probes. The up to two rows a voxel shares with its neighbours are searched the same
+// way, with the neighbours' places masked out. No wavefront waits for another, and a crowded voxel is shared out over
+// as many wavefronts as it has rows.
+#define RT_ORDER_BATCH 4               // straddling rows read together
+
+// number of entries below `key` in 64 ascending entries
+__device__ __forceinline__ uint32_t probe64(const uint32_t* s0, uint32_t key) {
+    uint32_t n0 = 0;
 #pragma unroll
-                for (uint32_t st = 32; st > 0; st >>= 1) n0 += (s0[n0 + st - 1u] < me1) ? st : 0u;
-                n0 += (s0[n0] < me1) ? 1u : 0u;
-                cnt += n0;
-            }
-        }
-    }
-    return cnt;
+    for (uint32_t st = 32; st > 0; st >>= 1) n0 += (s0[n0 + st - 1u] < key) ? st : 0u;
+    n0 += (s0[n0] < key) ? 1u : 0u;
+    return n0;
 }
 
 __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
-    __shared__ __attribute__((aligned(16))) uint32_t ids_all[4 * RT_ORDER_LDS_IDS];
+    __shared__ __attribute__((aligned(16))) uint32_t park_all[4][RT_ORDER_BATCH * 64];
     const uint32_t n_refs = b.grid->n_refs;
     if (n_refs > b.ref_cap) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t* park = park_all[wv];
+    const uint32_t n_waves = gridDim.x * 4, wave = blockIdx.x * 4 + wv;
     const uint32_t n_rows = (n_refs + 63u) / 64u;
-    const uint32_t n_quads = (n_rows + 3u) / 4u;            // a block takes four consecutive rows at a time
-    // The inputs of a quad (voxel, index, the voxel's range, first and last voxel of the quad) are fetched one quad ahead:
-    // the kernel is a chain of dependent round trips per quad, and this takes two of them off the chain.
-    struct QuadIn { uint32_t c, me, beg, end, c_first, c_last; };
-    auto fetch = [&](uint32_t quad, QuadIn& q) {
-        q.c = 0xffffffffu; q.me = 0; q.beg = 0; q.end = 0; q.c_first = 0; q.c_last = 1;
-        if (quad >= n_quads) return;
-        const uint32_t p = (quad * 4u + wv) * 64u + lane;
-        if (p < n_refs) { q.c = b.ref_cell[p]; q.me = b.ref_tri[p]; q.beg = b.cell_start[q.c]; q.end = b.cell_start[q.c + 1]; }
-        if (quad * 256u + 255u < n_refs) { q.c_first = b.ref_cell[quad * 256u]; q.c_last = b.ref_cell[quad * 256u + 255u]; }
+    // a row's inputs are fetched one row ahead: two round trips off the dependent chain
+    struct RowIn { uint32_t c, me, beg, end; };
+    auto fetch = [&](uint32_t row, RowIn& q) {
+        q.c = 0xffffffffu; q.me = 0; q.beg = 0; q.end = 0;
+        const uint32_t p = row * 64u + lane;
+        if (row < n_rows && p < n_refs) { q.c = b.ref_cell[p]; q.me = b.ref_tri[p]; q.beg = b.cell_start[q.c]; q.end = b.cell_start[q.c + 1]; }
     };
-    QuadIn nxt;
-    fetch(blockIdx.x, nxt);
-    for (uint32_t quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
-        const QuadIn cur = nxt;
-        fetch(quad + gridDim.x, nxt);
-        const uint32_t p = (quad * 4u + wv) * 64u + lane;
+    RowIn nxt;
+    fetch(wave, nxt);
+    for (uint32_t row = wave; row < n_rows; row += n_waves) {
+        const RowIn cur = nxt;
+        fetch(row + n_waves, nxt);
+        const uint32_t p = row * 64u + lane;
         const bool valid = p < n_refs;
         const uint32_t c = cur.c, me = cur.me, beg = cur.beg, end = cur.end;
-        const uint32_t me1 = me + 1u;
-        uint32_t rank = 0;
         // the triangle's record is requested now and written once the rank is known
         float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
         if (valid) { const float4* r = b.tri_rec + 3ull * me; rec0 = r[0]; rec1 = r[1]; rec2 = r[2]; }
-        // Do all four rows lie in ONE voxel (the usual case inside a crowded voxel)? Then the voxel's index list is staged
-        // once for the whole block instead of once per wavefront. Every wavefront reads the same two words, so the
-        // branch is uniform over the block.
-        const bool shared = cur.c_first == cur.c_last;
-        if (shared) {
-            const uint32_t first = beg & ~63u;              // beg, end are the same in every lane of the block
-            rank -= beg - first;
-            for (uint32_t tile = first; tile < end; tile += 4 * RT_ORDER_LDS_IDS) {
-                const uint32_t nt = (((end - tile) < 4 * RT_ORDER_LDS_IDS ? (end - tile) : 4 * RT_ORDER_LDS_IDS) + 63u) & ~63u;
-                __syncthreads();                            // the previous tile has been read by everyone
-                for (uint32_t k = threadIdx.x; k < nt; k += 1024) {
-                    uint32_t v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t q = tile + k + 256u * j;
-                        v[j] = (q >= beg && q < end) ? b.ref_tri[q] + 1u : ((q < beg) ? 0u : 0xffffffffu);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (k + 256u * j < nt) ids_all[k + 256u * j] = v[j];
-                }
-                __syncthreads();
-                rank += count_below(ids_all, nt, me1, true);
+        uint32_t rank = 0;
+        unsigned long long rem = __ballot(valid);
+        while (rem) {
+            const int l = __ffsll((long long)rem) - 1;
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, l);
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)beg, l);
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)end, l);
+            const bool mem = valid && c == c0;
+            rem &= ~__ballot(mem);
+            // rows of the voxel: [in_lo, in_hi) lie inside it; the row before in_lo and the row in_hi may be shared
+            const uint32_t in_lo = (b0 + 63u) >> 6, in_hi = e0 >> 6;
+            // ---- shared rows: the voxel's part of the row, neighbours masked (0 below, 0xffffffff above; indices + 1)
+            uint32_t edge[2]; int n_edge = 0;
+            if ((b0 & 63u) != 0u) edge[n_edge++] = b0 >> 6;
+            if ((e0 & 63u) != 0u && (n_edge == 0 || (e0 >> 6) != edge[0])) edge[n_edge++] = e0 >> 6;
+            for (int k = 0; k < n_edge; ++k) {
+                const uint32_t q = edge[k] * 64u + lane;
+                park[k * 64 + lane] = (q >= b0 && q < e0) ? b.ref_tri[q] + 1u : ((q < b0) ? 0u : 0xffffffffu);
             }
-            __syncthreads();                                // before another quad reuses the tile
-        } else {
-            uint32_t* ids = ids_all + wv * RT_ORDER_LDS_IDS;
-            unsigned long long rem = __ballot(valid);
-            while (rem) {
-                const int l = __ffsll((long long)rem) - 1;
-                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)c, l);
-                const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)beg, l);
-                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)end, l);
-                const bool mem = valid && c == c0;
-                rem &= ~__ballot(mem);
-                const uint32_t first = b0 & ~63u;
-                if (mem) rank -= b0 - first;
-                for (uint32_t tile = first; tile < e0; tile += RT_ORDER_LDS_IDS) {
-                    const uint32_t nt = (((e0 - tile) < RT_ORDER_LDS_IDS ? (e0 - tile) : RT_ORDER_LDS_IDS) + 63u) & ~63u;   // whole rows
-                    for (uint32_t k = lane; k < nt; k += 256) {          // four rows per trip, their loads in flight together
-                        uint32_t v[4];
+            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < n_edge; ++k) {
+                if (mem) {
+                    uint32_t n0 = probe64(park + k * 64, me + 1u);
+                    const uint32_t row0 = edge[k] * 64u;
+                    if (row0 < b0) n0 -= b0 - row0;              // the masked places below the voxel were counted
+                    rank += n0;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- rows inside the voxel, 64 at a time: lane j looks after row base + j
+            for (uint32_t base = in_lo; base < in_hi; base += 64u) {
+                const uint32_t nb = (in_hi - base) < 64u ? (in_hi - base) : 64u;
+                uint2 mm = make_uint2(0xffffffffu, 0xffffffffu);
+                if ((uint32_t)lane < nb) mm = b.row_minmax[base + lane];
+                unsigned long long straddle = 0;
+                for (uint32_t j = 0; j < nb; ++j) {
+                    const uint32_t lo_id = (uint32_t)__builtin_amdgcn_readlane((int)mm.x, (int)j);
+                    const uint32_t hi_id = (uint32_t)__builtin_amdgcn_readlane((int)mm.y, (int)j);
+                    const bool whole = hi_id < me, none = !(lo_id < me);
+                    if (mem && whole) rank += 64u;
+                    if (__ballot(mem && !whole && !none)) straddle |= 1ull << j;
+                }
+                while (straddle) {
+                    uint32_t rows[RT_ORDER_BATCH]; int nr = 0;
+                    while (straddle && nr < RT_ORDER_BATCH) { rows[nr++] = base + (uint32_t)(__ffsll((long long)straddle) - 1); straddle &= straddle - 1; }
+                    uint32_t v[RT_ORDER_BATCH];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const uint32_t q = tile + k + 64u * j;
-                            v[j] = (q >= b0 && q < e0) ? b.ref_tri[q] + 1u : ((q < b0) ? 0u : 0xffffffffu);
-                        }
+                    for (int k = 0; k < RT_ORDER_BATCH; ++k) v[k] = b.ref_tri[(size_t)rows[k < nr ? k : 0] * 64u + lane];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (k + 64u * j < nt) ids[k + 64u * j] = v[j];
-                    }
+                    for (int k = 0; k < RT_ORDER_BATCH; ++k) park[k * 64 + lane] = v[k];
                     __builtin_amdgcn_wave_barrier();
-                    rank += count_below(ids, nt, me1, mem);
+                    for (int k = 0; k < nr; ++k) {
+                        const uint32_t* s0 = park + k * 64;
+                        if (mem && s0[0] < me && !(s0[63] < me)) rank += probe64(s0, me);
+                    }
                     __builtin_amdgcn_wave_barrier();
                 }
             }
