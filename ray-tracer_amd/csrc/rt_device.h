@@ -90,6 +90,7 @@ struct RtRenderWork {
 // Build-time scratch.
 struct RtBuildDev {
     float4* v0; float4* v1; float4* v2;
+    float2* tri_box;              // 3 float2 per triangle, made at upload: {lo.x, lo.y} {lo.z, hi.x} {hi.y, hi.z}
     float4* tri_rec;              // 3 float4 per triangle: the test record of the triangle (see emit_record), made at upload
     uint32_t n_tris;
     float cube_root;              // 3.f * powf((float)T, 1.f/3.f), evaluated on the host (libm)

@@ -65,6 +65,7 @@ struct rt_scene {
     uint32_t known_refs = 0;           // reference count of the current triangle list once measured
     bool refs_known = false;
     DevBuf<float4> v0, v1, v2, tri_rec;
+    DevBuf<float2> tri_box;
     DevBuf<float> d_mesh_color;
     DevBuf<RtGrid> d_grid;
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
@@ -117,7 +118,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->device >= 0) {
         (void)hipSetDevice(s->device);
-        s->v0.release(); s->v1.release(); s->v2.release(); s->tri_rec.release(); s->d_mesh_color.release(); s->d_grid.release();
+        s->v0.release(); s->v1.release(); s->v2.release(); s->tri_rec.release(); s->tri_box.release(); s->d_mesh_color.release(); s->d_grid.release();
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
         s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->row_minmax.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); s->queue_lists.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
@@ -312,7 +313,7 @@ static int scene_bind_device(rt_scene* s) {
 
 static RtBuildDev build_args(rt_scene* s) {
     RtBuildDev b;
-    b.v0 = s->v0.p; b.v1 = s->v1.p; b.v2 = s->v2.p; b.tri_rec = s->tri_rec.p;
+    b.v0 = s->v0.p; b.v1 = s->v1.p; b.v2 = s->v2.p; b.tri_rec = s->tri_rec.p; b.tri_box = s->tri_box.p;
     b.n_tris = (uint32_t)s->tri_mesh.size();
     b.cube_root = 3.f * powf((float)s->tri_mesh.size(), 1.f / 3.f);   // Serial/grid.h:94, host libm
     b.grid = s->d_grid.p;
@@ -331,7 +332,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     if (s->uploaded) return RT_OK;
     const size_t T = s->tri_mesh.size();
     const size_t Tn = T ? T : 1;
-    if ((rc = s->v0.ensure(Tn)) || (rc = s->v1.ensure(Tn)) || (rc = s->v2.ensure(Tn)) || (rc = s->tri_rec.ensure(3 * Tn))) return rc;
+    if ((rc = s->v0.ensure(Tn)) || (rc = s->v1.ensure(Tn)) || (rc = s->v2.ensure(Tn)) || (rc = s->tri_rec.ensure(3 * Tn)) || (rc = s->tri_box.ensure(3 * Tn))) return rc;
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||

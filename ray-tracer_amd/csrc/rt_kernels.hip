@@ -54,7 +54,7 @@ __device__ __forceinline__ float dec_f32(uint32_t u) {
 // (e1.y*e2.z - e2.y*e1.z), the one 2x2 minor of Triangle::Intersect (Serial/geometry.h:131-177) that does not depend on
 // the ray. The grid build copies these records into voxel order.
 __global__ void k_upload_convert(const float* __restrict__ tri9, const uint32_t* __restrict__ mesh, float4* v0, float4* v1,
-                                 float4* v2, float4* tri_rec, uint32_t n) {
+                                 float4* v2, float4* tri_rec, float2* tri_box, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* t = tri9 + 9ull * i;
@@ -65,6 +65,11 @@ __global__ void k_upload_convert(const float* __restrict__ tri9, const uint32_t*
     const float e2x = t[0] - t[6], e2y = t[1] - t[7], e2z = t[2] - t[8];
     const double m = (double)e1y * (double)e2z - (double)e2y * (double)e1z;
     const unsigned long long mb = (unsigned long long)__double_as_longlong(m);
+    // the triangle's axis-aligned box (exact: minima and maxima of floats), all the grid build needs of the vertices
+    float2* bx = tri_box + 3ull * i;
+    bx[0] = make_float2(fminf(t[0], fminf(t[3], t[6])), fminf(t[1], fminf(t[4], t[7])));
+    bx[1] = make_float2(fminf(t[2], fminf(t[5], t[8])), fmaxf(t[0], fmaxf(t[3], t[6])));
+    bx[2] = make_float2(fmaxf(t[1], fmaxf(t[4], t[7])), fmaxf(t[2], fmaxf(t[5], t[8])));
     float4* o = tri_rec + 3ull * i;
     o[0] = make_float4(t[0], t[1], t[2], __uint_as_float(i));
     o[1] = make_float4(e1x, e1y, e1z, __uint_as_float((uint32_t)mb));
@@ -73,7 +78,7 @@ __global__ void k_upload_convert(const float* __restrict__ tri9, const uint32_t*
 
 hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh, RtBuildDev b, hipStream_t st) {
     if (b.n_tris == 0) return hipSuccess;
-    k_upload_convert<<<(b.n_tris + 255) / 256, 256, 0, st>>>(d_tri9, d_mesh, b.v0, b.v1, b.v2, b.tri_rec, b.n_tris);
+    k_upload_convert<<<(b.n_tris + 255) / 256, 256, 0, st>>>(d_tri9, d_mesh, b.v0, b.v1, b.v2, b.tri_rec, b.tri_box, b.n_tris);
     return hipGetLastError();
 }
 
@@ -90,16 +95,25 @@ __global__ void k_build_init(RtBuildDev b) {
     if (i == 6) { b.grid->n_refs = 0; b.grid->overflow = 0; }
 }
 
-// Scene bounds (Serial/grid.h:82-86): min/max over all vertices. Exact and order-independent.
+// Scene bounds (Serial/grid.h:82-86): min/max over all vertices, taken over the triangles' boxes. Exact and
+// order-independent.
 __global__ void __launch_bounds__(256) k_bounds(RtBuildDev b) {
     __shared__ float red[4][6];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n_tris; i += stride) {
-        float4 a = b.v0[i], c = b.v1[i], d = b.v2[i];
-        lo[0] = fminf(lo[0], fminf(a.x, fminf(c.x, d.x))); hi[0] = fmaxf(hi[0], fmaxf(a.x, fmaxf(c.x, d.x)));
-        lo[1] = fminf(lo[1], fminf(a.y, fminf(c.y, d.y))); hi[1] = fmaxf(hi[1], fmaxf(a.y, fmaxf(c.y, d.y)));
-        lo[2] = fminf(lo[2], fminf(a.z, fminf(c.z, d.z))); hi[2] = fmaxf(hi[2], fmaxf(a.z, fmaxf(c.z, d.z)));
+    // four triangles per trip: twelve loads in flight per lane
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < b.n_tris; i0 += 4 * stride) {
+        float2 a[4], c[4], d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + k * stride < b.n_tris ? i0 + k * stride : i0;
+            a[k] = b.tri_box[3ull * i]; c[k] = b.tri_box[3ull * i + 1]; d[k] = b.tri_box[3ull * i + 2];   // lo.xy, lo.z hi.x, hi.yz
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[0] = fminf(lo[0], a[k].x); lo[1] = fminf(lo[1], a[k].y); lo[2] = fminf(lo[2], c[k].x);
+            hi[0] = fmaxf(hi[0], c[k].y); hi[1] = fmaxf(hi[1], d[k].x); hi[2] = fmaxf(hi[2], d[k].y);
+        }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -152,9 +166,9 @@ __global__ void k_grid_setup(RtBuildDev b) {
 
 // Voxel range of one triangle's bounding box, Serial/grid.h:121-131.
 __device__ __forceinline__ void tri_voxel_range(const RtBuildDev& b, const RtGrid& g, uint32_t i, int vmin[3], int vmax[3]) {
-    float4 p = b.v0[i], q = b.v1[i], r = b.v2[i];
-    float lo[3] = {fminf(p.x, fminf(q.x, r.x)), fminf(p.y, fminf(q.y, r.y)), fminf(p.z, fminf(q.z, r.z))};
-    float hi[3] = {fmaxf(p.x, fmaxf(q.x, r.x)), fmaxf(p.y, fmaxf(q.y, r.y)), fmaxf(p.z, fmaxf(q.z, r.z))};
+    const float2 p = b.tri_box[3ull * i], q = b.tri_box[3ull * i + 1], r = b.tri_box[3ull * i + 2];
+    float lo[3] = {p.x, p.y, q.x};
+    float hi[3] = {q.y, r.x, r.y};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         vmin[a] = pos_to_voxel(lo[a], g.lo[a], g.inv_width[a], g.n[a]);
@@ -496,7 +510,7 @@ hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st) {
     k_build_init<<<256, 256, 0, st>>>(b);
     if (b.n_tris) {
         uint32_t nb = (b.n_tris + 255) / 256;
-        k_bounds<<<nb < 512 ? nb : 512, 256, 0, st>>>(b);
+        k_bounds<<<nb < 256 ? nb : 256, 256, 0, st>>>(b);
     }
     k_grid_setup<<<1, 64, 0, st>>>(b);
     if (b.n_tris) k_count<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
