@@ -335,16 +335,34 @@ __global__ void __launch_bounds__(256) k_row_sort(RtBuildDev b) {
     const uint32_t n_rows = (n_refs + 63u) / 64u;
     for (uint32_t row = wave; row < n_rows; row += n_waves) {
         const uint32_t p = row * 64u + lane;
-        unsigned long long key = ~0ull;
-        if (p < n_refs) key = ((unsigned long long)b.ref_cell[p] << 32) | b.ref_tri[p];
+        uint32_t cell = 0xffffffffu, tri = 0xffffffffu;
+        if (p < n_refs) { cell = b.ref_cell[p]; tri = b.ref_tri[p]; }
+        unsigned long long key;
+        if (__builtin_amdgcn_readlane((int)cell, 0) == __builtin_amdgcn_readlane((int)cell, 63)) {
+            // the whole row lies in one voxel (the usual case): the triangle index alone is the key
+            uint32_t k32 = tri;
 #pragma unroll
-        for (int k = 2; k <= 64; k <<= 1) {
+            for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                const unsigned long long other = __shfl_xor(key, j);
-                const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-                const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
-                key = (lower == up) ? mn : mx;
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const uint32_t other = __shfl_xor(k32, j);
+                    const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+                    const uint32_t mn = k32 < other ? k32 : other, mx = k32 < other ? other : k32;
+                    k32 = (lower == up) ? mn : mx;
+                }
+            }
+            key = k32;
+        } else {
+            key = ((unsigned long long)cell << 32) | tri;
+#pragma unroll
+            for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    const unsigned long long other = __shfl_xor(key, j);
+                    const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+                    const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+                    key = (lower == up) ? mn : mx;
+                }
             }
         }
         if (p < n_refs) b.ref_tri[p] = (uint32_t)key;
