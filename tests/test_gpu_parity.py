@@ -191,3 +191,52 @@ def test_unit_sizes_and_cost_classes_do_not_change_the_image(rt, plane10, monkey
         g_ids, g_rgb = golden(name)
         check_image(rgb, ids, g_rgb, g_ids)
         s.close()
+
+
+def _rows_against_oracle(rt, O, s, o, W, H, row_blocks, walk_mode):
+    """Whole frame on the GPU, sampled row blocks on the CPU oracle (full walk, as the reference runs)."""
+    rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=walk_mode))
+    n_id = 0
+    for y0, y1 in row_blocks:
+        o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0), y0=y0, y1=y1)
+        k, _ = check_image(rgb[y0:y1], ids[y0:y1], o_rgb, o_ids, exact=(walk_mode == rt.RT_WALK_FULL))
+        n_id += k
+    return n_id, rgb, ids
+
+
+def test_full_size_standin_4k_rows_against_oracle(rt, O):
+    """The benchmark's own frame: 3,637,248 triangles at 3840x2160. Voxels hold up to several thousand triangles here,
+    which is what exercises the run culling of crowded voxels; the small golden scenes never do."""
+    tmp = rt.Scene(); tmp.load_mesh(BLUB)
+    v9 = rt.subdivide(tmp.triangles(), 4); tmp.close()
+    s = rt.Scene(); s.add_triangles(v9)
+    o = O.OracleScene(); o.add_triangles(v9)
+    W, H = 3840, 2160
+    # row blocks spread over the rows the mesh covers (found on the GPU image; the comparison itself is per pixel)
+    _, _, ids0 = s.render(rt.default_params(W, H))
+    hit_rows = np.flatnonzero((ids0 >= 0).any(axis=1))
+    assert len(hit_rows) > 200
+    blocks = [(int(y), int(y) + 5) for y in hit_rows[np.linspace(0, len(hit_rows) - 6, 16).astype(int)]]
+    blocks.append((0, 2))                                       # and a strip of pure background
+    n_full, rgb_f, ids_f = _rows_against_oracle(rt, O, s, o, W, H, blocks, rt.RT_WALK_FULL)
+    assert n_full == 0
+    n_early, rgb_e, ids_e = _rows_against_oracle(rt, O, s, o, W, H, blocks, rt.RT_WALK_EARLY)
+    assert n_early <= 4
+    # size-independent properties over the WHOLE frame: the two walk modes agree (up to documented ties), every hit id
+    # is a triangle of the scene, background pixels are black
+    assert int((ids_f != ids_e).sum()) <= 16
+    assert ids_f.max() < v9.shape[0] and ids_f.min() >= -1
+    assert float(np.abs(rgb_f[ids_f < 0]).max(initial=0.0)) == 0.0
+
+
+def test_full_size_plane_4k_rows_against_oracle(rt, O, tmp_path):
+    """plane_mesh_creator.py at SQUARES_PER_UNIT=100 (2,004,002 triangles), 3840x2160: a flat 64x1x64 grid, every ray hits."""
+    path = str(tmp_path / "plane100.obj")
+    rt.make_plane_obj(path, 100)
+    s = rt.Scene(); s.load_mesh(path)
+    o = O.OracleScene(); o.add_obj(path)
+    blocks = [(y, y + 2) for y in range(40, 2160, 400)]
+    n_full, _, ids = _rows_against_oracle(rt, O, s, o, 3840, 2160, blocks, rt.RT_WALK_FULL)
+    assert n_full == 0
+    n_early, _, _ = _rows_against_oracle(rt, O, s, o, 3840, 2160, blocks, rt.RT_WALK_EARLY)
+    assert n_early <= 4
