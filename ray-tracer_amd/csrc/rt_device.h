@@ -57,7 +57,7 @@ struct RtSceneDev {
     const uint32_t* cell_start;   // n_cells + 1
     const uint32_t* occupancy;    // 1 bit per cell
     const float4* recs;           // 3 float4 per reference, cell-major, ascending triangle index in a cell
-    const float4* blk_bounds;     // 2 float4 per aligned run of 64 references: {lo.xyz, max |coord|}, {hi.xyz, 0}
+    const float4* blk_bounds;     // 3 float4 per aligned run of 64 references: {lo.xyz, max |coord|}, {hi.xyz, slab min}, {slab normal, slab max}
 };
 
 struct RtOutputs {
@@ -104,7 +104,7 @@ struct RtBuildDev {
     uint32_t* ref_cell;           // ref_cap: voxel of each unsorted reference
     uint2* row_minmax;            // per row of 64 references: smallest and largest triangle index after k_row_sort
     float4* recs;                 // 3 * ref_cap
-    float4* blk_bounds;           // 2 * (ref_cap / 64 + 1)
+    float4* blk_bounds;           // 3 * (ref_cap / 64 + 2)
     uint32_t ref_cap;
     unsigned long long* counters;
 };

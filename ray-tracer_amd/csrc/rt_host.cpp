@@ -375,7 +375,7 @@ static int build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_phase1
         s->h_grid = g;
         s->refs_known = true;
         size_t need = g.n_refs ? g.n_refs : 1;
-        if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)) || (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(2 * (need / 64 + 2)))) return rc;
+        if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)) || (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(3 * (need / 64 + 2)))) return rc;
     } else {
         HIP_TRY(rt_launch_build_phase1(build_args(s), st));
     }

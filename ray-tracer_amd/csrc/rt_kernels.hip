@@ -483,9 +483,14 @@ __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
     }
 }
 
-// BLOCK BOUNDS: the axis-aligned box of the triangles of every aligned run of 64 records (lo.xyz + largest
-// absolute coordinate, hi.xyz). The render kernel skips a run when a ray's line clearly misses its box; the
-// reference would test those triangles and find that none passes.
+__device__ __forceinline__ float bcast_f32(float v, int src_lane);
+
+// BLOCK BOUNDS of every aligned run of 64 records: the axis-aligned box of its triangles (lo.xyz + largest absolute
+// coordinate, hi.xyz) and a slab: a unit vector n (the run's summed triangle normals; consecutive triangles of a mesh
+// form a nearly flat patch) with the smallest and largest n.v over the run's vertices. All triangles of the run lie
+// inside the box AND between the slab's two planes, so a ray can only hit one of them where its line is inside both
+// at once. The render kernel skips a run when that clearly never happens; the reference would test those triangles
+// and find that none passes. Any n gives a valid slab (a folded patch just gives a thick one).
 __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
     const uint32_t n_refs = b.grid->n_refs;
     if (n_refs > b.ref_cap) return;
@@ -495,16 +500,29 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
     for (uint32_t blk = wave; blk < n_blk; blk += n_waves) {
         const uint32_t p = blk * 64u + lane;
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        if (p < n_refs) {
+        float vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0}, vz[3] = {0, 0, 0};      // the triangle's vertices
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        const bool have = p < n_refs;
+        if (have) {
             // the vertices as the record gives them: v0, v0 - e1, v0 - e2. Rebuilding v1 and v2 from the rounded edge
             // vectors is off by at most one unit in the last place of the larger operand, two orders of magnitude below
-            // the margin the box test adds.
+            // the margin the box and slab tests add.
             const float4 r0 = b.recs[3ull * p], r1 = b.recs[3ull * p + 1], r2 = b.recs[3ull * p + 2];
-            const float q1x = r0.x - r1.x, q1y = r0.y - r1.y, q1z = r0.z - r1.z;
-            const float q2x = r0.x - r2.x, q2y = r0.y - r2.y, q2z = r0.z - r2.z;
-            lo[0] = fminf(r0.x, fminf(q1x, q2x)); hi[0] = fmaxf(r0.x, fmaxf(q1x, q2x));
-            lo[1] = fminf(r0.y, fminf(q1y, q2y)); hi[1] = fmaxf(r0.y, fmaxf(q1y, q2y));
-            lo[2] = fminf(r0.z, fminf(q1z, q2z)); hi[2] = fmaxf(r0.z, fmaxf(q1z, q2z));
+            vx[0] = r0.x; vy[0] = r0.y; vz[0] = r0.z;
+            vx[1] = r0.x - r1.x; vy[1] = r0.y - r1.y; vz[1] = r0.z - r1.z;
+            vx[2] = r0.x - r2.x; vy[2] = r0.y - r2.y; vz[2] = r0.z - r2.z;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[0] = fminf(lo[0], vx[k]); hi[0] = fmaxf(hi[0], vx[k]);
+                lo[1] = fminf(lo[1], vy[k]); hi[1] = fmaxf(hi[1], vy[k]);
+                lo[2] = fminf(lo[2], vz[k]); hi[2] = fmaxf(hi[2], vz[k]);
+            }
+            nx = r1.y * r2.z - r1.z * r2.y; ny = r1.z * r2.x - r1.x * r2.z; nz = r1.x * r2.y - r1.y * r2.x;    // e1 x e2
+        }
+        // normals that point against the first triangle's are turned round before they are summed
+        {
+            const float fx = bcast_f32(nx, 0), fy = bcast_f32(ny, 0), fz = bcast_f32(nz, 0);
+            if (nx * fx + ny * fy + nz * fz < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -514,12 +532,29 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
                 hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
             }
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { nx += __shfl_xor(nx, off); ny += __shfl_xor(ny, off); nz += __shfl_xor(nz, off); }
+        {
+            const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+            if (len > 1e-30f && len < 1e30f) { nx /= len; ny /= len; nz /= len; } else { nx = 0.f; ny = 0.f; nz = 0.f; }
+        }
+        float dmin = INFINITY, dmax = -INFINITY;
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d = nx * vx[k] + ny * vy[k] + nz * vz[k];
+                dmin = fminf(dmin, d); dmax = fmaxf(dmax, d);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { dmin = fminf(dmin, __shfl_xor(dmin, off)); dmax = fmaxf(dmax, __shfl_xor(dmax, off)); }
         if (lane == 0) {
             float m = 0.f;
 #pragma unroll
             for (int a = 0; a < 3; ++a) m = fmaxf(m, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
-            b.blk_bounds[2ull * blk] = make_float4(lo[0], lo[1], lo[2], m);
-            b.blk_bounds[2ull * blk + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+            b.blk_bounds[3ull * blk] = make_float4(lo[0], lo[1], lo[2], m);
+            b.blk_bounds[3ull * blk + 1] = make_float4(hi[0], hi[1], hi[2], dmin);
+            b.blk_bounds[3ull * blk + 2] = make_float4(nx, ny, nz, dmax);
         }
     }
 }
@@ -1058,27 +1093,33 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         const uint32_t org = cull ? (cbeg & ~63u) : cbeg;
         const uint32_t nrun_me = (cend - org + 63u) >> 6;
         unsigned long long need0 = ~0ull, need1 = ~0ull, any0 = ~0ull, any1 = ~0ull;
-        // FP32 slab test of a ray's whole line against a run's box. Every slab is widened by
-        // mg = 4e-6 * (largest |coordinate| of the box + |origin|), more than 20 times the rounding error of the
-        // expressions below, so a line that touches the true box is always kept; fminf/fmaxf drop NaNs (0 * inf),
-        // which keeps the run as well.
-        auto box_hit = [](const float4 q0, const float4 q1, float rox, float roy, float roz, float rix, float riy, float riz) -> bool {
+        // FP32 test of a ray's whole line against a run's box and slab (k_block_bounds): the parameter interval in which
+        // the line is inside the box must overlap the one in which it is between the slab's planes. Box faces and slab
+        // planes are moved outwards by mg = 4e-6 (8e-6 for the slab) * (largest |coordinate| of the box + |origin|), more
+        // than 20 times the rounding error of the expressions below and of the stored bounds, so a line that touches a
+        // triangle of the run is always kept; fminf/fmaxf drop NaNs (0 * inf), which keeps the run as well, and so does a
+        // line parallel to the slab whose origin lies inside it (-inf .. +inf).
+        auto box_hit = [](const float4 q0, const float4 q1, const float4 q2, float rox, float roy, float roz, float rix, float riy, float riz,
+                          float rdx, float rdy, float rdz) -> bool {
             const float mg = 4e-6f * (q0.w + (fabsf(rox) + fabsf(roy) + fabsf(roz))) + 1e-30f;
             const float ax0 = ((q0.x - mg) - rox) * rix, ax1 = ((q1.x + mg) - rox) * rix;
             const float ay0 = ((q0.y - mg) - roy) * riy, ay1 = ((q1.y + mg) - roy) * riy;
             const float az0 = ((q0.z - mg) - roz) * riz, az1 = ((q1.z + mg) - roz) * riz;
-            const float t0 = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
-            const float t1 = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+            const float n_o = q2.x * rox + q2.y * roy + q2.z * roz, n_d = q2.x * rdx + q2.y * rdy + q2.z * rdz;
+            const float inv = 1.0f / n_d;
+            const float s0 = ((q1.w - 2.f * mg) - n_o) * inv, s1 = ((q2.w + 2.f * mg) - n_o) * inv;
+            const float t0 = fmaxf(fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1)), fminf(s0, s1));
+            const float t1 = fminf(fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1)), fmaxf(s0, s1));
             return !(t0 > t1);
         };
         // (a) voxels with up to RT_CULL_LANE_RUNS runs: lane = ray, a short loop over the runs of its own voxel,
         //     all voxels of the round at once
         if (cull && nrun_me <= (cull_min >> 16)) {
-            const float4* bb = s.blk_bounds + 2ull * (org >> 6);
+            const float4* bb = s.blk_bounds + 3ull * (org >> 6);
             need0 = 0;
 #pragma unroll 4
             for (uint32_t k = 0; k < nrun_me; ++k)
-                if (box_hit(bb[2 * k], bb[2 * k + 1], ox, oy, oz, ifx, ify, ifz)) need0 |= 1ull << k;
+                if (box_hit(bb[3 * k], bb[3 * k + 1], bb[3 * k + 2], ox, oy, oz, ifx, ify, ifz, dx, dy, dz)) need0 |= 1ull << k;
         }
         // (b) more crowded voxels, one after the other: lane = run (up to 128 of them), the rays standing in the voxel
         //     are broadcast one by one; runs from 128 on are always tested
@@ -1091,18 +1132,19 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 const uint32_t vo = (uint32_t)__builtin_amdgcn_readlane((int)org, leader) >> 6;
                 const unsigned long long mem = __ballot(cull && cbeg == vb);
                 dn &= ~mem;
-                float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+                float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, b0 = a0, b1 = a0, b2 = a0;
                 const bool h0 = (uint32_t)lane < vn, h1 = (uint32_t)lane + 64u < vn;
-                if (h0) { a0 = s.blk_bounds[2ull * (vo + lane)]; a1 = s.blk_bounds[2ull * (vo + lane) + 1]; }
-                if (h1) { b0 = s.blk_bounds[2ull * (vo + 64u + lane)]; b1 = s.blk_bounds[2ull * (vo + 64u + lane) + 1]; }
+                if (h0) { const float4* q = s.blk_bounds + 3ull * (vo + lane); a0 = q[0]; a1 = q[1]; a2 = q[2]; }
+                if (h1) { const float4* q = s.blk_bounds + 3ull * (vo + 64u + lane); b0 = q[0]; b1 = q[1]; b2 = q[2]; }
                 unsigned long long lm = mem, u0 = 0, u1 = 0;
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
                     lm &= lm - 1;
                     const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
                     const float rix = bcast_f32(ifx, i), riy = bcast_f32(ify, i), riz = bcast_f32(ifz, i);
-                    const unsigned long long m0 = __ballot(h0 && box_hit(a0, a1, rox, roy, roz, rix, riy, riz));
-                    const unsigned long long m1 = (vn > 64u) ? __ballot(h1 && box_hit(b0, b1, rox, roy, roz, rix, riy, riz)) : 0ull;
+                    const float rdx = bcast_f32(dx, i), rdy = bcast_f32(dy, i), rdz = bcast_f32(dz, i);
+                    const unsigned long long m0 = __ballot(h0 && box_hit(a0, a1, a2, rox, roy, roz, rix, riy, riz, rdx, rdy, rdz));
+                    const unsigned long long m1 = (vn > 64u) ? __ballot(h1 && box_hit(b0, b1, b2, rox, roy, roz, rix, riy, riz, rdx, rdy, rdz)) : 0ull;
                     if (lane == i) { need0 = m0; need1 = m1; }
                     u0 |= m0; u1 |= m1;
                 }
