@@ -43,6 +43,7 @@ struct RtFrame {
     float early_slack;
     int32_t count_work;           // 1 = the kernel also counts voxel steps and triangle tests
     uint64_t unit_shifts;         // 4 bits per queue list (list 0 lowest): log2 of the work units a tile of the list is cut into
+    int32_t adapt_units;          // 1: k_bucket enlarges the units when the frame lists many tiles per wavefront
     int32_t cull_min;             // voxels with at least this many triangles get the per-run box test
 };
 
@@ -72,7 +73,7 @@ struct RtOutputs {
 
 // Per-frame work list of the render kernels.
 struct RtRenderWork {
-    uint32_t* work;               // [0] listed tiles, [1] dequeue head, [RT_WORK_LIST_COUNTS..+15] tiles per queue list; zeroed before each frame
+    uint32_t* work;               // [0] listed tiles, [1] dequeue head, [RT_WORK_LIST_COUNTS..+15] tiles per queue list, [+16..+31] unit shift per list; zeroed before each frame
     uint32_t* tile_list;          // capacity = tiles of the frame
     uint32_t* cost;               // estimated cost per listed tile
     uint32_t* est_by_tile;        // diagnostics: the four estimate features, each indexed by tile of the frame (may be NULL)

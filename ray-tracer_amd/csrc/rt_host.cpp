@@ -89,6 +89,7 @@ struct rt_scene {
     // queue list (expensive 0..7 from the top down, cheap 8..11, in-between 12..15)
     float sched_thr0 = 1.f, sched_thr1 = 8.f;
     uint64_t sched_shifts = 0x2222000022223333ull;
+    bool sched_adapt = true;               // off when RT_SHIFTS gives the unit sizes explicitly
     float est_w[4] = {1.f, 500.f, 0.f, 700.f};    // cost estimate weights: primary triangles, primary voxels, shadow triangles, shadow voxels
     hipStream_t last_stream = nullptr;
     hipStream_t side_stream = nullptr;       // work-list preparation beside the grid build
@@ -108,7 +109,7 @@ extern "C" rt_scene* rt_scene_create(void) {
             const unsigned long long v = strtoull(e, &end, 16);
             bool ok = end && *end == 0;
             for (int k = 0; k < 16 && ok; ++k) ok = ((v >> (4 * k)) & 15ull) <= 4;
-            if (ok) s->sched_shifts = v;
+            if (ok) { s->sched_shifts = v; s->sched_adapt = false; }
         }
     }
     return s;
@@ -507,6 +508,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.early_slack = 0.f;
     f.count_work = s->count_work ? 1 : 0;
     f.unit_shifts = s->sched_shifts;
+    f.adapt_units = s->sched_adapt ? 1 : 0;
     { const char* e = getenv("RT_CULL_MIN"); const char* e2 = getenv("RT_CULL_LANE_RUNS"); f.cull_min = (e ? atoi(e) : 96) | ((e2 ? atoi(e2) : 12) << 16); }
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;

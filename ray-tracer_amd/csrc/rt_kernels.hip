@@ -940,11 +940,23 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
 // Every list has its own unit size (RtFrame::unit_shifts).
 __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* tile_list, const uint32_t* cost,
                                                 const unsigned long long* cost_sum, uint32_t* lists, uint32_t cap,
-                                                float div0, float div1, int n_waves) {
+                                                float div0, float div1, int n_waves, unsigned long long unit_shifts, int adapt) {
     const uint32_t n = work[0];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if (blockIdx.x * blockDim.x >= n) return;
+    // Unit sizes of the lists, for k_trace. The given sizes suit frames with about one listed tile per wavefront; with
+    // more tiles per wavefront there are enough units to balance the load anyway, and larger units are cheaper (the
+    // stepping, culling and shading of a unit cost the same for 16 rays as for 64): one size up from 2.5 tiles per
+    // wavefront, two from 10.
+    if (blockIdx.x == 0 && threadIdx.x < RT_QUEUE_LISTS) {
+        uint32_t sh = (uint32_t)((unit_shifts >> (4 * threadIdx.x)) & 15ull);
+        if (adapt) {
+            const uint32_t up = (2u * n >= 5u * (uint32_t)n_waves ? 1u : 0u) + (n >= 10u * (uint32_t)n_waves ? 1u : 0u);
+            sh = sh > up ? sh - up : 0u;
+        }
+        work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + threadIdx.x] = sh;
+    }
     const float share = (float)((double)*cost_sum / (double)n_waves);
     const float lim0 = fmaxf(share / div0, 1.f), lim1 = fmaxf(share / div1, 0.5f);
     int cls = -1;
@@ -1348,7 +1360,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
         const RtFrame& f = A->f;
         const RtOutputs& o = A->o;
         // units per list (lane k < 16 looks after list k), requested before the atomic so that both round trips overlap
-        const uint32_t my_shift = (lane < RT_QUEUE_LISTS) ? (uint32_t)((f.unit_shifts >> (4 * lane)) & 15ull) : 0u;
+        const uint32_t my_shift = (lane < RT_QUEUE_LISTS) ? work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + lane] : 0u;
         const uint32_t my_units = (lane < RT_QUEUE_LISTS) ? (work[RT_WORK_LIST_COUNTS + lane] << my_shift) : 0u;
         if (lane == 0) slot_next = atomicAdd(&work[1], 1u);
         const uint32_t slot = __builtin_amdgcn_readfirstlane(slot_next);
@@ -1504,7 +1516,8 @@ hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame
     const int nb = (n_cls + 255) / 256;
     k_estimate<<<(n_cls + 63) / 64, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles,
                                                                                         make_float4(wk.est_w[0], wk.est_w[1], wk.est_w[2], wk.est_w[3]));
-    k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.lists, wk.list_cap, wk.thr0, wk.thr1, trace_blocks(f, wk) * RT_WAVES_PER_BLOCK);
+    k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.lists, wk.list_cap, wk.thr0, wk.thr1, trace_blocks(f, wk) * RT_WAVES_PER_BLOCK,
+                                (unsigned long long)f.unit_shifts, f.adapt_units);
     return hipGetLastError();
 }
 
