@@ -87,7 +87,7 @@ struct rt_scene {
     // scheduling of the trace kernel: a tile is "expensive" when its estimate exceeds 1/thr0 of the even share of one
     // wavefront and "cheap" below 1/thr1 of it; unit_shifts holds log2 of the work units a tile is cut into, 4 bits per
     // queue list (expensive 0..7 from the top down, cheap 8..11, in-between 12..15)
-    float sched_thr0 = 1.f, sched_thr1 = 8.f;
+    float sched_thr0 = 1.f, sched_thr1 = 4.f;
     uint64_t sched_shifts = 0x2222000022223333ull;
     bool sched_adapt = true;               // off when RT_SHIFTS gives the unit sizes explicitly
     float est_w[4] = {1.f, 500.f, 0.f, 700.f};    // cost estimate weights: primary triangles, primary voxels, shadow triangles, shadow voxels
