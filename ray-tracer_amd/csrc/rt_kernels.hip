@@ -1152,7 +1152,10 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
                     lm &= lm - 1;
-                    const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
+                    // with a shared origin everything of the test that depends on the origin alone is the same for all
+                    // rays and leaves this loop
+                    const float rox = SHARED_ORIGIN ? bcast_f32(ox, 0) : bcast_f32(ox, i), roy = SHARED_ORIGIN ? bcast_f32(oy, 0) : bcast_f32(oy, i),
+                                roz = SHARED_ORIGIN ? bcast_f32(oz, 0) : bcast_f32(oz, i);
                     const float rix = bcast_f32(ifx, i), riy = bcast_f32(ify, i), riz = bcast_f32(ifz, i);
                     const float rdx = bcast_f32(dx, i), rdy = bcast_f32(dy, i), rdz = bcast_f32(dz, i);
                     const unsigned long long m0 = __ballot(h0 && box_hit(a0, a1, a2, rox, roy, roz, rix, riy, riz, rdx, rdy, rdz));
