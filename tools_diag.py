@@ -41,7 +41,10 @@ for w in sys.argv[1:]:
     order = np.argsort(np.argsort(-est_all))
     for u in top:
         t_ = int(qi[u] & 0xffffff)
-        print("      %9d slot %6d list %2d shift %d tile %8d rank %d" % (q[u], u, qi[u] >> 28, (qi[u] >> 24) & 15, act[t_], order[t_]))
+        print("      %9d slot %6d list %2d shift %d tile %8d rank %d | tile (x,y)=(%d,%d) features %s" % (q[u], u, qi[u] >> 28, (qi[u] >> 24) & 15, act[t_], order[t_],
+              t_ % ((W + 7) // 8), t_ // ((W + 7) // 8), feat[:, t_].astype(int).tolist()))
+    mm = act > 0
+    print("      feature medians over listed tiles", np.median(feat[:, mm], axis=1).astype(int).tolist(), "p90", np.percentile(feat[:, mm], 90, axis=1).astype(int).tolist(), "max", feat[:, mm].max(axis=1).astype(int).tolist())
     for l in range(16):
         sel = (qi >> 28) == l
         if sel.any(): print("      list %2d: units %6d mean %8.0f max %8.0f" % (l, sel.sum(), q[sel].mean(), q[sel].max()))
