@@ -1034,18 +1034,21 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 //   triangle test is then evaluated once per triangle instead of once per ray.
 //   early (primary rays): leave once the nearest hit so far lies before the next voxel crossing.
 //
-// The walk alternates two phases until every ray is done.
+// The walk goes in rounds of three phases until every ray is done.
 //   STEP  every live lane advances its own DDA through empty voxels (occupancy bitmap in LDS) until it stands
 //         in an occupied voxel or has left the grid.
-//   TEST  the live lanes are grouped by the voxel they stand in. For each such voxel the wavefront turns round:
-//         the voxel's triangle records are read 64 at a time, ONE PER LANE (consecutive 48-byte records, a
-//         coalesced stream straight from HBM/L2 into registers, next chunk prefetched), and the rays standing in
-//         the voxel are broadcast one after the other through scalar registers and tested against the 64
-//         triangles at once. A record is therefore loaded once per voxel visit of the tile, not once per ray,
-//         and lane utilisation is the voxel's fill of its last 64-chunk, whatever the number of rays sharing it.
+//   CULL  crowded voxels only: which 64-record runs of its voxel can a ray's line touch at all (box and slab of
+//         the run, see the comment at box_hit)?
+//   TEST  the live lanes are grouped by the voxel they stand in. The round's (voxel, needed run) pairs are streamed
+//         one after the other, two in flight: the run's triangle records are read ONE PER LANE (64 consecutive
+//         48-byte records, a coalesced stream into registers), and the rays that need the run are broadcast one
+//         after the other through scalar registers and tested against the 64 triangles at once. A record is
+//         therefore loaded once per voxel visit of the work unit, not once per ray, and lane utilisation is the
+//         run's fill, whatever the number of rays sharing it.
 //         The reference tests a voxel's triangles in ascending index and updates (global_t, nearest triangle)
-//         after each one; here the passing lanes of a chunk are applied in ascending lane order, which is the
-//         same order, so the float rounding of global_t between updates is reproduced.
+//         after each one; here the runs are visited in ascending order and the passing lanes of a run are applied in
+//         ascending lane order, which is the same order, so the float rounding of global_t between updates is
+//         reproduced.
 //
 // Triangle::Intersect (Serial/geometry.h:131-177): the four 3x3 determinants share their 2x2 minors over the
 // y,z rows; evaluating each minor once changes no bit because negating a minor is exact and the t1 - t2 + t3
