@@ -225,7 +225,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mrays/s (primary+shadow), nefertiti 4K" if args.workload.startswith("nefertiti") else "Mrays/s (primary+shadow)",
+            "metric": {"nefertiti4k": "Mrays/s (primary+shadow), nefertiti 4K", "nefertiti8k": "Mrays/s (primary+shadow), nefertiti 8K"}.get(args.workload, "Mrays/s (primary+shadow)"),
             "value": round(rays_total / (ms_per_step * 1e-3) / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
