@@ -240,3 +240,35 @@ def test_full_size_plane_4k_rows_against_oracle(rt, O, tmp_path):
     assert n_full == 0
     n_early, _, _ = _rows_against_oracle(rt, O, s, o, 3840, 2160, blocks, rt.RT_WALK_EARLY)
     assert n_early <= 4
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_crowded_voxels_with_awkward_geometry(rt, O, seed):
+    """Thousands of triangles per voxel (the run-culling paths of the trace kernel), without any mesh coherence: random
+    orientations, slivers, zero-area triangles, duplicates, a few triangles that span the whole scene. Every decision
+    must still be the reference's."""
+    rng = np.random.default_rng(seed)
+    n = 24000
+    clusters = rng.uniform(-0.6, 0.6, size=(12, 3)) * np.array([1.0, 0.3, 1.0])       # 2000 triangles within a voxel or two each
+    centre = (clusters[rng.integers(0, 12, size=n)] + rng.normal(size=(n, 3)) * 0.02)[:, None, :]
+    size = rng.choice([0.002, 0.02, 0.15], size=(n, 1, 1), p=[0.6, 0.37, 0.03])
+    tri = (centre + rng.normal(size=(n, 3, 3)) * size).astype(np.float32)
+    tri[::11, 2] = tri[::11, 1]                      # zero area: two equal vertices
+    tri[5::13, 2] = tri[5::13, 0] + (tri[5::13, 1] - tri[5::13, 0]) * np.float32(0.5)   # zero area: collinear
+    tri[7::17] = tri[6::17][: len(tri[7::17])]       # exact duplicates (ties: the lower index must win)
+    tri[-3:] = rng.uniform(-2.5, 2.5, size=(3, 3, 3)).astype(np.float32)               # scene-spanning triangles
+    tri[:, :, 1] -= 1.0                              # in front of the default camera, which looks at the origin from (3,5,3)
+    v9 = np.ascontiguousarray(tri.reshape(n, 9))
+    s = rt.Scene(); s.add_triangles(v9, (40, 200, 90))
+    o = O.OracleScene(); o.add_triangles(v9, (40, 200, 90))
+    W, H = 400, 300
+    o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0))
+    rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL))
+    check_image(rgb, ids, o_rgb, o_ids)
+    rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_EARLY))
+    n_id, _ = check_image(rgb, ids, o_rgb, o_ids, exact=False)
+    assert n_id <= 8
+    g = s.grid_info()
+    start, _ = s.grid_csr()
+    assert int(np.diff(start).max()) >= 1000, "the scene is meant to crowd its voxels"
+    assert int((o_ids >= 0).sum()) > W * H // 20
