@@ -1,6 +1,6 @@
 """Render one workload twice in separate processes' settings (env var given on the command line) and compare ids (GPU)."""
 import importlib, sys, os, subprocess, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 2 and sys.argv[1] == "--dump":
     import bench
     rt = importlib.import_module("ray-tracer_amd")

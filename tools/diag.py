@@ -1,7 +1,7 @@
 """Scheduling diagnostics of the trace kernel for one workload (GPU)."""
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 rt = importlib.import_module("ray-tracer_amd")
 for w in sys.argv[1:]:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench the listed workloads under several values of one environment variable: VAR=NAME VALS="a b c" tools_env.sh workload...
+# bench the listed workloads under several values of one environment variable: VAR=NAME VALS="a b c" tools/env.sh workload...
 mkdir -p gpurun_out
 for v in $VALS; do
   for w in "$@"; do

@@ -1,7 +1,7 @@
 """Experiment: two scenes of the same mesh rendered alternately on two streams -- how much does overlapping one frame's
 grid build with the other frame's trace tail buy? (GPU)"""
 import importlib, sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 rt = importlib.import_module("ray-tracer_amd")
 w = sys.argv[1] if len(sys.argv) > 1 else "nefertiti4k"

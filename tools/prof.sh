@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-kernel times of one workload: tools_prof.sh <workload> <tag>
+# per-kernel times of one workload: tools/prof.sh <workload> <tag>
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$2 -o $2 --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --workload $1 --steps 20 > $GRAFT_REPO_ROOT/gpurun_out/prof_$2.log 2>&1 || { tail -5 $GRAFT_REPO_ROOT/gpurun_out/prof_$2.log; exit 1; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM-side bytes of k_trace per launch from the L2 fabric counters, one rocprofv3 pass per counter:
-#   tools_traffic.sh <workload>  ->  gpurun_out/traffic_<workload>.json
+#   tools/traffic.sh <workload>  ->  gpurun_out/traffic_<workload>.json
 export TMPDIR=/tmp; R=$PWD; W=$1; O=$R/gpurun_out/traffic_$W; mkdir -p $O
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$C -o pmc -- python3 bench.py --no-cpu --steps 3 --warmup 1 --workload $W > $O/$C.json 2> $O/$C.err || { tail -3 $O/$C.err; exit 1; }
