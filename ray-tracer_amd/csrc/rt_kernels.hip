@@ -1121,7 +1121,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             const float ay0 = ((q0.y - mg) - roy) * riy, ay1 = ((q1.y + mg) - roy) * riy;
             const float az0 = ((q0.z - mg) - roz) * riz, az1 = ((q1.z + mg) - roz) * riz;
             const float n_o = q2.x * rox + q2.y * roy + q2.z * roz, n_d = q2.x * rdx + q2.y * rdy + q2.z * rdz;
-            const float inv = 1.0f / n_d;
+            const float inv = __builtin_amdgcn_rcpf(n_d);      // 1 ulp is far inside the margins; 0 gives inf like a division
             const float s0 = ((q1.w - 2.f * mg) - n_o) * inv, s1 = ((q2.w + 2.f * mg) - n_o) * inv;
             const float t0 = fmaxf(fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1)), fminf(s0, s1));
             const float t1 = fminf(fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1)), fmaxf(s0, s1));
