@@ -33,8 +33,9 @@ for w in sys.argv[1:]:
         pred = X @ wts
         print("   least squares weights", np.round(wts, 1), "corr(fit, measured) = %.3f" % np.corrcoef(pred, a)[0, 1])
         np.save("gpurun_out/diag_%s_feat.npy" % w, feat); np.save("gpurun_out/diag_%s_act.npy" % w, act)
-    q = c[:st["tiles_traced"]].astype(np.float64)        # unit costs in queue order
-    qi = info[:st["tiles_traced"]]
+    n_units = int(np.flatnonzero(c)[-1]) + 1 if c.any() else 0
+    q = c[:n_units].astype(np.float64)        # unit costs in queue order
+    qi = info[:n_units]
     top = np.argsort(q)[::-1][:12]
     print("   heaviest units (cycles, slot, list, shift, tile cycles, tile estimate rank):")
     est_all = 1.0 * feat[0] + 500.0 * feat[1] + 700.0 * feat[3]
