@@ -1464,6 +1464,14 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
                 if (lane == 0 && o.unit_cost) {
                     o.unit_cost[slot] = (uint32_t)cyc; atomicAdd(&o.tile_cycles[tile], (uint32_t)cyc);
                     o.unit_info[slot] = (uint32_t)tile | ((uint32_t)ushift << 24) | ((uint32_t)li << 28);
+                    // (run, ray) test iterations and record runs streamed by the unit, 18 + 14 bits, saturating
+                    const uint32_t ut = wp.trips + ws.trips, ui = wp.items + ws.items;
+                    const size_t n16 = (size_t)16 * ((f.width + RT_TILE - 1) / RT_TILE) * ((f.out_rows + RT_TILE - 1) / RT_TILE);
+                    o.unit_info[n16 + slot] = (ut > 0x3ffffu ? 0x3ffffu : ut) | ((ui > 0x3fffu ? 0x3fffu : ui) << 18);
+                    // cycles of the three phases in units of 256, and the rounds
+                    const uint32_t c_s = (wp.cyc_step + ws.cyc_step) >> 8, c_c = (wp.cyc_cull + ws.cyc_cull) >> 8, c_t = (wp.cyc_test + ws.cyc_test) >> 8;
+                    o.unit_info[2 * n16 + slot] = (c_s > 0xffffu ? 0xffffu : c_s) | ((c_c > 0xffffu ? 0xffffu : c_c) << 16);
+                    o.unit_info[3 * n16 + slot] = (c_t > 0xffffffu ? 0xffffffu : c_t) | ((wp.rounds + ws.rounds > 255u ? 255u : wp.rounds + ws.rounds) << 24);
                 }
             }
         }

@@ -19,9 +19,10 @@ for w in sys.argv[1:]:
           "| runs", st["runs_streamed"], "trips", st["run_ray_trips"], "cyc cull/tile", int(st["cycles_cull"] / t))
     print("   kernel span", st["span_cycles"], "busiest wave", st["wave_cycles_max"], "mean wave (4096)", int(st["tile_cycles_sum"] / 4096))
     nt = ((W + 7) // 8) * ((H + 7) // 8)
-    c = scene.unit_costs(nt * 64)
+    c = scene.unit_costs(nt * 96)
     feat = c[16 * nt:20 * nt].astype(np.float64).reshape(4, nt); act = c[20 * nt:21 * nt].astype(np.float64)
     info = c[21 * nt:37 * nt]
+    work_ = c[37 * nt:53 * nt]; ph1 = c[53 * nt:69 * nt]; ph2 = c[69 * nt:85 * nt]
     c = c[:16 * nt]
     m = act > 0
     if m.sum() > 10:
@@ -42,8 +43,8 @@ for w in sys.argv[1:]:
     order = np.argsort(np.argsort(-est_all))
     for u in top:
         t_ = int(qi[u] & 0xffffff)
-        print("      %9d slot %6d list %2d shift %d tile %8d rank %d | tile (x,y)=(%d,%d) features %s" % (q[u], u, qi[u] >> 28, (qi[u] >> 24) & 15, act[t_], order[t_],
-              t_ % ((W + 7) // 8), t_ // ((W + 7) // 8), feat[:, t_].astype(int).tolist()))
+        print("      %9d slot %6d list %2d shift %d tile %8d rank %d | tile (x,y)=(%d,%d) features %s | trips %d runs %d | step %dK cull %dK test %dK rounds %d" % (q[u], u, qi[u] >> 28, (qi[u] >> 24) & 15, act[t_], order[t_],
+              t_ % ((W + 7) // 8), t_ // ((W + 7) // 8), feat[:, t_].astype(int).tolist(), work_[u] & 0x3ffff, work_[u] >> 18, (ph1[u] & 0xffff) >> 2, (ph1[u] >> 16) >> 2, (ph2[u] & 0xffffff) >> 2, ph2[u] >> 24))
     mm = act > 0
     print("      feature medians over listed tiles", np.median(feat[:, mm], axis=1).astype(int).tolist(), "p90", np.percentile(feat[:, mm], 90, axis=1).astype(int).tolist(), "max", feat[:, mm].max(axis=1).astype(int).tolist())
     for l in range(16):
@@ -55,6 +56,25 @@ for w in sys.argv[1:]:
         for x in costs:
             heapq.heapreplace(h, h[0] + x)
         return max(h)
+    def latest(costs, lists_, nw=4096, top=8):
+        h = [(0.0, i) for i in range(nw)]
+        heapq.heapify(h)
+        ends = []
+        for j, x in enumerate(costs):
+            t0_, wv = heapq.heappop(h)
+            heapq.heappush(h, (t0_ + x, wv))
+            ends.append((t0_ + x, t0_, x, int(lists_[j]), j))
+        last_start = max(e[1] for e in ends)
+        ends.sort(reverse=True)
+        print("   simulated: last unit starts at %.0f; latest-ending units (end, start, cost, list, slot):" % last_start)
+        for e in ends[:top]: print("      %.0f %.0f %.0f list %d slot %d" % e)
+        fin = sorted(t for t, _ in h)
+        print("   simulated wave end times: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (fin[len(fin)//10], fin[len(fin)//2], fin[len(fin)*9//10], fin[len(fin)*99//100], fin[-1]))
+    latest(q, qi >> 28)
+    tr = (work_[:n_units] & 0x3ffff).astype(np.float64); it = (work_[:n_units] >> 18).astype(np.float64)
+    X = np.vstack([tr, it, np.ones(n_units)]).T
+    wts, *_ = np.linalg.lstsq(X, q, rcond=None)
+    print("   unit cycles ~ %.0f * trips + %.0f * runs + %.0f (corr %.3f); totals: trips %.0f runs %.0f" % (wts[0], wts[1], wts[2], np.corrcoef(X @ wts, q)[0, 1], tr.sum(), it.sum()))
     print("   simulated greedy makespan: queue order %.0f | sorted descending %.0f | mean load %.0f | max unit %.0f" % (
         makespan(q), makespan(np.sort(q)[::-1]), q.sum() / 4096, q.max()))
     c = c[c > 0].astype(np.float64)
