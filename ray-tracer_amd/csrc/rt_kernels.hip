@@ -1059,6 +1059,9 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 //   gnum  = e1.x*P(s,d)  -  s.x*P(e1,d) + d.x*P(e1,s)
 // The divisions are only executed when the signs allow beta > 0 and gamma > 0 and the numerators allow
 // beta + gamma < 1 with a 1e-12 relative margin; inside that margin the reference's own expression decides.
+#ifndef RT_STEPS_PER_ROUND
+#define RT_STEPS_PER_ROUND 8
+#endif
 template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT>
 __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* bitmap, int lane, bool active, float ox,
                                           float oy, float oz, float dx, float dy, float dz, float mint, bool use_eps, float eps,
@@ -1087,15 +1090,20 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             alive = dda_advance(w, early && hit, st.t, slack);
             if (COUNT && alive) ++wc.steps;
         }
-        first = false;
-        while (alive && !((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u)) {
+        // at most RT_STEPS_PER_ROUND empty voxels per round: a ray on a long empty stretch goes on in the next round
+        // instead of keeping the others waiting (it takes part in this round with an empty voxel)
+        int steps_left = RT_STEPS_PER_ROUND;
+        while (alive && !((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u) && steps_left > 0) {
             alive = dda_advance(w, early && hit, st.t, slack);
             if (COUNT && alive) ++wc.steps;
+            --steps_left;
         }
-        unsigned long long un = __ballot(alive);
-        if (!un) break;
+        if (!__ballot(alive)) break;
+        const bool at_voxel = alive && ((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u);
+        first = !at_voxel;                               // a ray still under way has not looked at its voxel yet
+        unsigned long long un = __ballot(at_voxel);
         uint32_t cbeg = 0, cend = 0;
-        if (alive) { cbeg = s.cell_start[w.cell]; cend = s.cell_start[w.cell + 1]; }
+        if (at_voxel) { cbeg = s.cell_start[w.cell]; cend = s.cell_start[w.cell + 1]; }
         const long long t1 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (COUNT) { wc.rounds += 1; wc.cyc_step += (uint32_t)(t1 - t0); if (alive) wc.tests += cend - cbeg; }
         // ---- CULL (crowded voxels only): every ray against the boxes of the 64-record runs of ITS voxel, lane = ray.
@@ -1184,7 +1192,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     const int leader = __ffsll((long long)un) - 1;
                     sb = (uint32_t)__builtin_amdgcn_readlane((int)cbeg, leader);
                     se = (uint32_t)__builtin_amdgcn_readlane((int)cend, leader);
-                    smem = __ballot(alive && cbeg == sb);
+                    smem = __ballot(at_voxel && cbeg == sb);
                     un &= ~smem;
                     scull = (se - sb) >= (cull_min & 0xffffu);
                     sorg = scull ? (sb & ~63u) : sb;
