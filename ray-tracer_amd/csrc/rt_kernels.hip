@@ -1027,6 +1027,11 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
     return t;
 }
 
+// empty voxels a ray may cross in one round of wave_walk before the round goes on without it
+#ifndef RT_STEPS_PER_ROUND
+#define RT_STEPS_PER_ROUND 8
+#endif
+
 // GridAccel::Intersect (Serial/grid.h:167-231) for the 64 rays of a wavefront at once. Every lane must call it.
 //   ANY_HIT: the shadow query. The reference ORs every voxel's result over the whole walk and ignores t,
 //   so leaving at the first passing triangle returns the same value.
@@ -1059,9 +1064,6 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 //   gnum  = e1.x*P(s,d)  -  s.x*P(e1,d) + d.x*P(e1,s)
 // The divisions are only executed when the signs allow beta > 0 and gamma > 0 and the numerators allow
 // beta + gamma < 1 with a 1e-12 relative margin; inside that margin the reference's own expression decides.
-#ifndef RT_STEPS_PER_ROUND
-#define RT_STEPS_PER_ROUND 8
-#endif
 template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT>
 __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* bitmap, int lane, bool active, float ox,
                                           float oy, float oz, float dx, float dy, float dz, float mint, bool use_eps, float eps,
@@ -1254,11 +1256,12 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     const double A = t.e1x * p_e2d - t.e2x * p_e1d + rdx * t.m12;
                     const double bnum = sx * p_e2d - t.e2x * p_sd - rdx * p_e2s;
                     const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
-                    const bool pos = (A > 0.0) && (bnum > 0.0) && (gnum > 0.0);
-                    const bool neg = (A < 0.0) && (bnum < 0.0) && (gnum < 0.0);
+                    // beta > 0 and gamma > 0 need A, bnum and gnum of one sign: three integer operations on the sign bits
+                    // instead of six double compares (zeros and NaNs get through here and fail the exact test below)
+                    const bool one_sign = ((__double2hiint(A) ^ __double2hiint(bnum)) | (__double2hiint(A) ^ __double2hiint(gnum))) >= 0;
                     bool pass = false;
                     double tt = 0.0;
-                    if (have && (pos || neg) && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12))) {
+                    if (have && one_sign && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12))) {
                         const double beta = bnum / A;
                         const double gamma = gnum / A;
                         if (beta > 0 && gamma > 0 && beta + gamma < 1) {
