@@ -1258,21 +1258,23 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
                     // beta > 0 and gamma > 0 need A, bnum and gnum of one sign: three integer operations on the sign bits
                     // instead of six double compares (zeros and NaNs get through here and fail the exact test below)
-                    const bool one_sign = ((__double2hiint(A) ^ __double2hiint(bnum)) | (__double2hiint(A) ^ __double2hiint(gnum))) >= 0;
-                    bool pass = false;
+                    int ha = __double2hiint(A), hb = __double2hiint(bnum), hg = __double2hiint(gnum);
+                    asm("" : "+v"(ha), "+v"(hb), "+v"(hg));           // keeps the test on the upper halves (32-bit operations)
+                    const bool one_sign = ((ha ^ hb) | (ha ^ hg)) >= 0;
+                    const bool cand = have && one_sign && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12));
+                    // the rest runs for the whole wavefront when any lane is a candidate: no lane masks to save and restore,
+                    // and the pass mask comes straight from the compares
+                    unsigned long long pm = 0;
                     double tt = 0.0;
-                    if (have && one_sign && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12))) {
+                    if (__ballot(cand)) {
                         const double beta = bnum / A;
                         const double gamma = gnum / A;
-                        if (beta > 0 && gamma > 0 && beta + gamma < 1) {
-                            pass = true;
-                            if (!ANY_HIT) {
-                                const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
-                                tt = tnum / A;
-                            }
+                        pm = __ballot(cand && beta > 0 && gamma > 0 && beta + gamma < 1);
+                        if (!ANY_HIT && pm) {
+                            const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
+                            tt = tnum / A;
                         }
                     }
-                    unsigned long long pm = __ballot(pass);
                     if (pm) {
                         if (ANY_HIT) {
                             if (lane == i) {
