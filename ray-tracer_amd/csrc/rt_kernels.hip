@@ -1230,8 +1230,9 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         auto process = [&](const Item& cur, const TriRec& t) {
             const uint32_t base = cur.base, e = cur.e;
             const bool have = base + lane >= cur.b && base + lane < e;
+            const unsigned long long have_m = __ballot(have);
             unsigned long long lm = cur.rays & __ballot(alive);          // rays that were hit meanwhile (shadow query) drop out
-            if (COUNT) { wc.lanes += (uint32_t)__popcll(__ballot(have)) * (uint32_t)__popcll(lm); wc.items += 1; wc.trips += (uint32_t)__popcll(lm); }
+            if (COUNT) { wc.lanes += (uint32_t)__popcll(have_m) * (uint32_t)__popcll(lm); wc.items += 1; wc.trips += (uint32_t)__popcll(lm); }
             if (lm) {
                 // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
                 double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
@@ -1258,18 +1259,20 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
                     // beta > 0 and gamma > 0 need A, bnum and gnum of one sign: three integer operations on the sign bits
                     // instead of six double compares (zeros and NaNs get through here and fail the exact test below)
-                    int ha = __double2hiint(A), hb = __double2hiint(bnum), hg = __double2hiint(gnum);
-                    asm("" : "+v"(ha), "+v"(hb), "+v"(hg));           // keeps the test on the upper halves (32-bit operations)
-                    const bool one_sign = ((ha ^ hb) | (ha ^ hg)) >= 0;
-                    const bool cand = have && one_sign && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12));
-                    // the rest runs for the whole wavefront when any lane is a candidate: no lane masks to save and restore,
-                    // and the pass mask comes straight from the compares
+                    // Lane masks straight from the compares (predicates as in llvm::CmpInst: 38 signed >, 13 unordered or <=,
+                    // 2 ordered >, 4 ordered <). beta > 0 and gamma > 0 need A, bnum and gnum of one sign: one three-input
+                    // bit operation on the upper halves, (a ^ b) | (a ^ c), sign bit clear (zeros and NaNs get through here
+                    // and fail the exact test below).
+                    uint32_t sgn;
+                    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x7e" : "=v"(sgn) : "v"(__double2hiint(A)), "v"(__double2hiint(bnum)), "v"(__double2hiint(gnum)));
+                    const unsigned long long cand = have_m & __builtin_amdgcn_sicmp((int)sgn, -1, 38) &
+                                                    __builtin_amdgcn_fcmp(fabs(bnum + gnum), fabs(A) * (1.0 + 1e-12), 13);
                     unsigned long long pm = 0;
                     double tt = 0.0;
-                    if (__ballot(cand)) {
+                    if (cand) {
                         const double beta = bnum / A;
                         const double gamma = gnum / A;
-                        pm = __ballot(cand && beta > 0 && gamma > 0 && beta + gamma < 1);
+                        pm = cand & __builtin_amdgcn_fcmp(beta, 0.0, 2) & __builtin_amdgcn_fcmp(gamma, 0.0, 2) & __builtin_amdgcn_fcmp(beta + gamma, 1.0, 4);
                         if (!ANY_HIT && pm) {
                             const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
                             tt = tnum / A;
