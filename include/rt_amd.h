@@ -144,6 +144,11 @@ int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n);
 /* Work accounting: when enabled, frames also count voxel steps and triangle tests per ray class. */
 int rt_scene_set_counting(rt_scene* s, int32_t enable);
 
+/* Self-test of the arithmetic of the triangle test (no counterpart in the reference): the kernels divide three
+ * numerators by one denominator with a shared reciprocal refinement where the operands' exponents are within 2^+-300;
+ * this runs that form and the plain division on the n pairs (num[i], den[i]) on the GPU and returns the number of
+ * pairs whose results differ in any bit (pairs outside the exponent window are skipped), or a negative rt_status. */
+int64_t rt_selftest_division(const double* num, const double* den, int64_t n);
 /* Band de-interleave after a gather: src holds part_count stacked partial frames of rt_part_rows() rows
  * each (rank-major), dst is the full row-major frame. elem_bytes = bytes per pixel (12, 3 or 4). */
 int rt_deinterleave_device(const rt_params* p, const void* d_src, void* d_dst, int32_t elem_bytes, void* stream);

@@ -64,7 +64,7 @@ EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
     "rt_render_device", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_unit_costs",
-    "rt_deinterleave_device",
+    "rt_deinterleave_device", "rt_selftest_division",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
 
@@ -114,6 +114,8 @@ def lib():
     if hasattr(L, "rt_scene_unit_costs"):
         L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
     L.rt_deinterleave_device.argtypes = [vp, vp, vp, i32, vp]
+    L.rt_selftest_division.argtypes = [vp, vp, i64]
+    L.rt_selftest_division.restype = i64
     L.rt_write_ppm.argtypes = [C.c_char_p, vp, i32, i32]
     L.rt_write_ppm_u8.argtypes = [C.c_char_p, vp, i32, i32]
     L.rt_make_plane_obj.argtypes = [C.c_char_p, i32]
@@ -268,6 +270,16 @@ def deinterleave_host(params, stacked):
 
 def deinterleave_device(params, d_src, d_dst, elem_bytes, stream=None):
     _check(lib().rt_deinterleave_device(C.byref(params), d_src, d_dst, elem_bytes, stream))
+
+
+def selftest_division(num, den):
+    """rt_selftest_division: pairs for which the shared-reciprocal division differs from the plain one (GPU)."""
+    num = np.ascontiguousarray(num, dtype=np.float64); den = np.ascontiguousarray(den, dtype=np.float64)
+    assert num.shape == den.shape and num.ndim == 1
+    r = lib().rt_selftest_division(num.ctypes.data, den.ctypes.data, num.size)
+    if r < 0:
+        _check(int(r))
+    return int(r)
 
 
 def write_ppm(path, rgb_f32):

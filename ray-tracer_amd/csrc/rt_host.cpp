@@ -598,6 +598,30 @@ extern "C" int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_
     return RT_OK;
 }
 
+extern "C" int64_t rt_selftest_division(const double* num, const double* den, int64_t n) {
+    if (n < 0 || (n > 0 && (!num || !den)) || n > (int64_t)1 << 30) return set_err(RT_ERR_INVALID, "rt_selftest_division: bad argument");
+    {
+        int n_dev = 0;
+        hipError_t e0 = hipGetDeviceCount(&n_dev);
+        if (e0 != hipSuccess || n_dev <= 0) return set_err(RT_ERR_NO_DEVICE, "no HIP device: %s", e0 == hipSuccess ? "count is 0" : hipGetErrorString(e0));
+    }
+    if (n == 0) return 0;
+    double *d_num = nullptr, *d_den = nullptr;
+    uint32_t* d_bad = nullptr;
+    uint32_t bad = 0;
+    hipError_t e = hipMalloc(&d_num, n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_den, n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_num, num, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_den, den, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = rt_launch_selftest_div(d_num, d_den, (uint32_t)n, d_bad, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_num); (void)hipFree(d_den); (void)hipFree(d_bad);
+    if (e != hipSuccess) return set_err(RT_ERR_HIP, "rt_selftest_division: %s", hipGetErrorString(e));
+    return (int64_t)bad;
+}
+
 extern "C" int rt_scene_set_counting(rt_scene* s, int32_t enable) {
     if (!s) return set_err(RT_ERR_INVALID, "rt_scene_set_counting: NULL scene");
     s->count_work = enable != 0;

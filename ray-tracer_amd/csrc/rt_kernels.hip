@@ -1009,6 +1009,41 @@ __device__ __forceinline__ double minor_f32(double a, double b, double c, double
     return __builtin_fma(a, b, -(c * d));
 }
 
+// Division with a shared reciprocal. The f64 division of this target is the sequence: scale both operands, v_rcp_f64
+// of the denominator, two Newton steps, quotient estimate, residual, one fused correction (+ post-scaling), fix-up of
+// special operands. When the biased exponents of numerator and denominator lie within 1023 +- 300 nothing is scaled and
+// nothing is fixed up, so the steps up to the refined reciprocal depend on the denominator alone: div_rcp() is that
+// part, div_with_rcp() the rest. Together they execute the same instructions on the same values as `num / den`.
+__device__ __forceinline__ double div_rcp(double den) {
+    double y = __builtin_amdgcn_rcp(den);
+    y = __builtin_fma(y, __builtin_fma(-den, y, 1.0), y);
+    y = __builtin_fma(y, __builtin_fma(-den, y, 1.0), y);
+    return y;
+}
+__device__ __forceinline__ double div_with_rcp(double num, double den, double y) {
+    const double q = num * y;
+    return __builtin_fma(__builtin_fma(-den, q, num), y, q);
+}
+__device__ __forceinline__ uint32_t exponent_field(double x) { return ((uint32_t)__double2hiint(x) >> 20) & 0x7ffu; }
+#define RT_DIV_EXP_LO (1023u - 300u)
+#define RT_DIV_EXP_HI (1023u + 300u)
+
+// Self-test of the shared-reciprocal division: count the pairs for which it differs from the plain division.
+__global__ void k_selftest_div(const double* __restrict__ num, const double* __restrict__ den, uint32_t n, uint32_t* mismatches) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = num[i], b = den[i];
+    const uint32_t ea = exponent_field(a), eb = exponent_field(b);
+    if (ea < RT_DIV_EXP_LO || ea > RT_DIV_EXP_HI || eb < RT_DIV_EXP_LO || eb > RT_DIV_EXP_HI) return;
+    const double fast = div_with_rcp(a, b, div_rcp(b)), plain = a / b;
+    if (__double_as_longlong(fast) != __double_as_longlong(plain)) atomicAdd(mismatches, 1u);
+}
+hipError_t rt_launch_selftest_div(const double* num, const double* den, uint32_t n, uint32_t* mismatches, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    k_selftest_div<<<(n + 255) / 256, 256, 0, st>>>(num, den, n, mismatches);
+    return hipGetLastError();
+}
+
 // One triangle record as a lane holds it during the test phase.
 struct TriRec {
     float v0x, v0y, v0z;
@@ -1270,12 +1305,30 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     unsigned long long pm = 0;
                     double tt = 0.0;
                     if (cand) {
-                        const double beta = bnum / A;
-                        const double gamma = gnum / A;
+                        // The three quotients have one denominator: where the exponents of all operands allow it (see
+                        // div_rcp) the reciprocal part of the division is evaluated once. Any candidate lane outside the
+                        // window (zeros, infinities and NaNs included) sends the wavefront down the plain path.
+                        const uint32_t ea = exponent_field(A), eb = exponent_field(bnum), eg = exponent_field(gnum);
+                        const uint32_t e_lo = min(min(ea, eb), eg), e_hi = max(max(ea, eb), eg);
+                        const bool fast = (cand & ~(__builtin_amdgcn_uicmp(e_lo, RT_DIV_EXP_LO, 35) & __builtin_amdgcn_uicmp(e_hi, RT_DIV_EXP_HI, 37))) == 0ull;
+                        double beta, gamma, rcp_a = 0.0;
+                        if (fast) {
+                            rcp_a = div_rcp(A);
+                            beta = div_with_rcp(bnum, A, rcp_a);
+                            gamma = div_with_rcp(gnum, A, rcp_a);
+                        } else {
+                            beta = bnum / A;
+                            gamma = gnum / A;
+                        }
                         pm = cand & __builtin_amdgcn_fcmp(beta, 0.0, 2) & __builtin_amdgcn_fcmp(gamma, 0.0, 2) & __builtin_amdgcn_fcmp(beta + gamma, 1.0, 4);
                         if (!ANY_HIT && pm) {
                             const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
-                            tt = tnum / A;
+                            const uint32_t et = exponent_field(tnum);
+                            if (fast && (pm & ~(__builtin_amdgcn_uicmp(et, RT_DIV_EXP_LO, 35) & __builtin_amdgcn_uicmp(et, RT_DIV_EXP_HI, 37))) == 0ull) {
+                                tt = div_with_rcp(tnum, A, rcp_a);
+                            } else {
+                                tt = tnum / A;
+                            }
                         }
                     }
                     if (pm) {

@@ -272,3 +272,26 @@ def test_crowded_voxels_with_awkward_geometry(rt, O, seed):
     start, _ = s.grid_csr()
     assert int(np.diff(start).max()) >= 1000, "the scene is meant to crowd its voxels"
     assert int((o_ids >= 0).sum()) > W * H // 20
+
+
+def test_shared_reciprocal_division_is_the_plain_division(rt):
+    """The triangle test divides beta, gamma and t by one determinant with a shared reciprocal refinement
+    (Triangle::Intersect, Serial/geometry.h:150-162, three divisions by A). On the GPU, both forms must agree in every
+    bit: random magnitudes over the whole exponent window, operands like the test's (small integers' ratios, values next
+    to powers of two, quotients next to 0, 1 and to ties), and denominators with all-ones mantissas."""
+    rng = np.random.default_rng(7)
+    n = 1 << 20
+    mant = lambda k: rng.uniform(1.0, 2.0, k)
+    sign = lambda k: rng.choice([-1.0, 1.0], k)
+    num = [sign(n) * mant(n) * np.exp2(rng.integers(-290, 290, n)), sign(n) * mant(n) * np.exp2(rng.integers(-40, 40, n))]
+    den = [sign(n) * mant(n) * np.exp2(rng.integers(-290, 290, n)), sign(n) * mant(n) * np.exp2(rng.integers(-40, 40, n))]
+    # structured cases
+    a = rng.integers(1, 1 << 24, n).astype(np.float64); b = rng.integers(1, 1 << 24, n).astype(np.float64)
+    num.append(a); den.append(b)                                              # float-valued operands
+    num.append(np.nextafter(b, rng.choice([-np.inf, np.inf], n))); den.append(b)   # quotients next to 1
+    d = mant(n); q = rng.integers(1, 1 << 52, n).astype(np.float64) * 2.0 ** -52 + 1.0
+    num.append(d * q + rng.choice([-1, 0, 1], n) * np.spacing(d * q)); den.append(d)   # near exactly representable quotients
+    num.append(sign(n) * mant(n)); den.append(np.nextafter(np.exp2(rng.integers(-100, 100, n).astype(np.float64)), 0.0))   # all-ones mantissas
+    num = np.concatenate(num); den = np.concatenate(den)
+    assert rt.selftest_division(num, den) == 0
+    assert rt.selftest_division(np.zeros(0), np.zeros(0)) == 0
