@@ -138,7 +138,9 @@ int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stats* out);
  * estimate of every tile is made of, [20t, 21t) shader cycles per tile, [21t, 37t) per work unit: tile | unit shift << 24
  * | queue list << 28, [37t, 53t) per work unit: (run, ray) test iterations | record runs streamed << 18 (both saturate),
  * [53t, 69t) per work unit: cycles / 256 spent stepping | cycles / 256 spent culling runs << 16, [69t, 85t) per work
- * unit: cycles / 256 spent testing | rounds << 24. 96t words in all. Returns the number of words copied (at most n).
+ * unit: cycles / 256 spent testing | rounds << 24, [85t, 101t) per work unit: its start on the 100 MHz
+ * real-time clock (low 20 bits) | its duration on that clock / 64 << 20.
+ * 112t words in all. Returns the number of words copied (at most n).
  * No counterpart in the reference. */
 int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n);
 /* Work accounting: when enabled, frames also count voxel steps and triangle tests per ray class. */

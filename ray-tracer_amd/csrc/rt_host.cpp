@@ -537,8 +537,8 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         const size_t tiles = (size_t)((p->width + 7) / 8) * (size_t)((f.out_rows + 7) / 8);
         if ((rc = s->tile_list.ensure(tiles ? tiles : 1))) return rc;
         if (s->count_work) {
-            if ((rc = s->unit_cost.ensure((tiles ? tiles : 1) * 96))) return rc;
-            HIP_TRY(hipMemsetAsync(s->unit_cost.p, 0, (tiles ? tiles : 1) * 96 * sizeof(uint32_t), side));
+            if ((rc = s->unit_cost.ensure((tiles ? tiles : 1) * 112))) return rc;
+            HIP_TRY(hipMemsetAsync(s->unit_cost.p, 0, (tiles ? tiles : 1) * 112 * sizeof(uint32_t), side));
             // layout: 16 x tiles unit slots, the four estimate features and the measured cycles of every tile of the frame,
             // then 16 x tiles unit descriptions
             o.unit_cost = s->unit_cost.p; o.tile_cycles = s->unit_cost.p + 20 * tiles; o.unit_info = s->unit_cost.p + 21 * tiles; wk.est_by_tile = s->unit_cost.p + 16 * tiles;
@@ -561,6 +561,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         const size_t lds = rt_trace_lds_bytes(wk.bitmap_words);
         int per_cu = (int)((160 * 1024) / lds);
         wk.blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+        { const char* e = getenv("RT_BLOCKS_PER_CU"); if (e && atoi(e) >= 1 && atoi(e) < wk.blocks_per_cu) wk.blocks_per_cu = atoi(e); }   // experiment override
 
     }
     HIP_TRY(rt_launch_render_prep(sd, cam, sh, f, wk, side));

@@ -1471,6 +1471,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
         Nearest st = {INFINITY, -1};
         WalkCount wp = {}, ws = {};
         const long long t_start = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        const unsigned long long rt_start = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
         const bool hit = wave_walk<false, true, COUNT>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
                                                        sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, st, wp);
         float cr = 0.f, cg = 0.f, cb = 0.f;
@@ -1540,6 +1541,10 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
                     // cycles of the three phases in units of 256, and the rounds
                     const uint32_t c_s = (wp.cyc_step + ws.cyc_step) >> 8, c_c = (wp.cyc_cull + ws.cyc_cull) >> 8, c_t = (wp.cyc_test + ws.cyc_test) >> 8;
                     o.unit_info[2 * n16 + slot] = (c_s > 0xffffu ? 0xffffu : c_s) | ((c_c > 0xffffu ? 0xffffu : c_c) << 16);
+                    // start and duration on the 100 MHz real-time clock (the shader clock is not the same on all dies):
+                    // start in the low 20 bits, duration / 64 above, saturating
+                    const uint32_t rt_dur = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt_start) >> 6;
+                    o.unit_info[4 * n16 + slot] = ((uint32_t)rt_start & 0xfffffu) | ((rt_dur > 0xfffu ? 0xfffu : rt_dur) << 20);
                     o.unit_info[3 * n16 + slot] = (c_t > 0xffffffu ? 0xffffffu : c_t) | ((wp.rounds + ws.rounds > 255u ? 255u : wp.rounds + ws.rounds) << 24);
                 }
             }

@@ -19,10 +19,10 @@ for w in sys.argv[1:]:
           "| runs", st["runs_streamed"], "trips", st["run_ray_trips"], "cyc cull/tile", int(st["cycles_cull"] / t))
     print("   kernel span", st["span_cycles"], "busiest wave", st["wave_cycles_max"], "mean wave (4096)", int(st["tile_cycles_sum"] / 4096))
     nt = ((W + 7) // 8) * ((H + 7) // 8)
-    c = scene.unit_costs(nt * 96)
+    c = scene.unit_costs(nt * 112)
     feat = c[16 * nt:20 * nt].astype(np.float64).reshape(4, nt); act = c[20 * nt:21 * nt].astype(np.float64)
     info = c[21 * nt:37 * nt]
-    work_ = c[37 * nt:53 * nt]; ph1 = c[53 * nt:69 * nt]; ph2 = c[69 * nt:85 * nt]
+    work_ = c[37 * nt:53 * nt]; ph1 = c[53 * nt:69 * nt]; ph2 = c[69 * nt:85 * nt]; t0s = c[85 * nt:101 * nt]
     c = c[:16 * nt]
     m = act > 0
     if m.sum() > 10:
@@ -71,6 +71,16 @@ for w in sys.argv[1:]:
         fin = sorted(t for t, _ in h)
         print("   simulated wave end times: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (fin[len(fin)//10], fin[len(fin)//2], fin[len(fin)*9//10], fin[len(fin)*99//100], fin[-1]))
     latest(q, qi >> 28)
+    # measured time line: units by start and end (clock wraps are ignored: a frame is far shorter than 2^32 cycles)
+    raw = t0s[:n_units].astype(np.int64); ok_ = q > 0
+    st_ = raw & 0xfffff; st_ = ((st_ - st_[0] + (1 << 19)) & 0xfffff) - (1 << 19); st_ = st_ - st_[ok_].min(); en_ = st_ + (raw >> 20) * 64
+    T = en_[ok_].max()
+    print("   measured (10 ns ticks): kernel %.0f; last unit starts at %.0f; units still running after the last start: %d" % (T, st_[ok_].max(), (en_[ok_] > st_[ok_].max()).sum()))
+    for frac in (0.5, 0.6, 0.7, 0.8, 0.9):
+        tcut = frac * T
+        run = ok_ & (st_ <= tcut) & (en_ > tcut)
+        ls = (qi >> 28)[run]
+        print("      at %.0f%% of the kernel: %4d units running (lists 0-7: %d, 8-11: %d, 12-15: %d), started at t=0..5%%: %d" % (100 * frac, run.sum(), (ls < 8).sum(), ((ls >= 8) & (ls < 12)).sum(), (ls >= 12).sum(), (st_[run] < 0.05 * T).sum()))
     tr = (work_[:n_units] & 0x3ffff).astype(np.float64); it = (work_[:n_units] >> 18).astype(np.float64)
     X = np.vstack([tr, it, np.ones(n_units)]).T
     wts, *_ = np.linalg.lstsq(X, q, rcond=None)
