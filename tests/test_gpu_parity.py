@@ -295,3 +295,46 @@ def test_shared_reciprocal_division_is_the_plain_division(rt):
     num = np.concatenate(num); den = np.concatenate(den)
     assert rt.selftest_division(num, den) == 0
     assert rt.selftest_division(np.zeros(0), np.zeros(0)) == 0
+
+
+VIEWS = {
+    # camera inside the grid bounds (boundingBox::Inside branch of GridAccel::Intersect, Serial/grid.h:172-175)
+    "camera_inside_the_grid": dict(cam_pos=(0.1, 0.2, 0.1), cam_target=(1.5, 0.0, 0.0), fov=70.0),
+    # centre ray exactly along -y: direction components are 0 and 1/0 appears in the slab and DDA set-up
+    "looking_down_an_axis": dict(cam_pos=(0.25, 6.0, 0.25), cam_target=(0.25, 0.0, 0.25), cam_up=(0.0, 0.0, 1.0), fov=30.0),
+    # other shading constants: general pow(), another light, shadow scale and eps (Serial/raytracer.cpp:82-117)
+    "other_shading_constants": dict(light_pos=(-4.0, 3.0, 6.0), kd=0.7, ks=3.0, ka=0.05, spec_alpha=2.5, light_intensity=100.0,
+                                    shadow_scale=0.5, eps=0.01),
+    # wide angle from far away: most rays miss, the hits are crowded into few tiles
+    "far_and_wide": dict(cam_pos=(30.0, 50.0, 30.0), cam_target=(0.0, 0.0, 0.0), fov=10.0),
+    # grazing view along the meshes
+    "grazing": dict(cam_pos=(-3.0, 0.05, 0.0), cam_target=(3.0, 0.0, 0.0), fov=40.0),
+}
+
+
+@pytest.mark.parametrize("view", list(VIEWS))
+def test_other_cameras_and_shading_against_oracle(rt, O, view):
+    kw = VIEWS[view]
+    s = rt.Scene(); s.load_mesh(SPOT); s.load_mesh(BLUB, True, (0, 200, 255), (1.5, 0, 0))
+    o = O.OracleScene(); o.add_obj(SPOT); o.add_obj(BLUB, True, (0, 200, 255), (1.5, 0, 0))
+    W, H = 320, 200
+    o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0, **kw))
+    assert (o_ids >= 0).sum() > 50, "the view must see the meshes"
+    rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL, **kw))
+    check_image(rgb, ids, o_rgb, o_ids)
+    rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_EARLY, **kw))
+    n_id, _ = check_image(rgb, ids, o_rgb, o_ids, exact=False)
+    assert n_id <= 2
+
+
+def test_mesh_far_from_the_origin(rt, O):
+    """Large coordinates: the margins of the run culling scale with |box| + |origin| (offset 4000, camera beside it)."""
+    off = (4000.0, -2500.0, 3000.0)
+    s = rt.Scene(); s.load_mesh(SPOT, True, (255, 0, 0), off)
+    o = O.OracleScene(); o.add_obj(SPOT, True, (255, 0, 0), off)
+    kw = dict(cam_pos=(off[0] + 3, off[1] + 5, off[2] + 3), cam_target=off, light_pos=(off[0] + 5, off[1] - 5, off[2] + 2))
+    W, H = 256, 256
+    o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0, **kw))
+    assert (o_ids >= 0).sum() > 1000
+    rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL, **kw))
+    check_image(rgb, ids, o_rgb, o_ids)
