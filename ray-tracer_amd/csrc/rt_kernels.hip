@@ -788,35 +788,35 @@ __device__ __forceinline__ void dda_setup(Dda& w, const GridU& g, float ox, floa
 // stepAxis comes from the 3-bit compare table {2,1,2,1,2,2,0,0}: axis 0 iff next0 < next1 and next0 < next2,
 // axis 1 iff not (next0 < next1) and next1 < next2, else axis 2. Written without branches on the axis.
 __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t, float slack, float* crossed_t = nullptr) {
-    // Copies that the optimiser has to treat as register values: without them it rewrites the selects below as one
-    // load from a selected address, which pins the whole state in scratch memory.
-    float n0 = w.next0, n1 = w.next1, n2 = w.next2, d0 = w.delta0, d1 = w.delta1, d2 = w.delta2;
-    int l0 = w.left0, l1 = w.left1, l2 = w.left2, c0 = w.cstep0, c1 = w.cstep1, c2 = w.cstep2;
-    asm("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(d0), "+v"(d1), "+v"(d2));
-    asm("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(c0), "+v"(c1), "+v"(c2));
+    // The optimiser has to treat the state as register values: without this it rewrites the selects below as one load
+    // from a selected address, which pins the whole state in scratch memory. (In place: no copies are made.)
+    asm("" : "+v"(w.next0), "+v"(w.next1), "+v"(w.next2), "+v"(w.delta0), "+v"(w.delta1), "+v"(w.delta2));
+    asm("" : "+v"(w.left0), "+v"(w.left1), "+v"(w.left2), "+v"(w.cstep0), "+v"(w.cstep1), "+v"(w.cstep2));
+    const float n0 = w.next0, n1 = w.next1, n2 = w.next2;
     const bool c01 = n0 < n1, c02 = n0 < n2, c12 = n1 < n2;
     const bool is0 = c01 && c02;
     const bool is1 = !c01 && c12;
     const bool is2 = !(is0 || is1);
     const float nx_t = is0 ? n0 : (is1 ? n1 : n2);
-    if (early_hit) {
-        const float lim = best_t + fabsf(best_t) * slack;
-        if (lim < nx_t) return false;
+    const int lf = is0 ? w.left0 : (is1 ? w.left1 : w.left2);
+    // the ray is done when it has a hit nearer than the next voxel (early exit) or stands in the last voxel of the
+    // axis it would leave through (Pos[stepAxis] == Out[stepAxis]); one branch for both
+    const float lim = best_t + fabsf(best_t) * slack;
+    const bool go = !((early_hit && lim < nx_t) || lf == 0);
+    if (go) {
+        const float dl = is0 ? w.delta0 : (is1 ? w.delta1 : w.delta2);
+        const int cs = is0 ? w.cstep0 : (is1 ? w.cstep1 : w.cstep2);
+        if (crossed_t) *crossed_t = nx_t;
+        const float nn = nx_t + dl;
+        w.next0 = is0 ? nn : n0;
+        w.next1 = is1 ? nn : n1;
+        w.next2 = is2 ? nn : n2;
+        w.left0 = is0 ? lf - 1 : w.left0;
+        w.left1 = is1 ? lf - 1 : w.left1;
+        w.left2 = is2 ? lf - 1 : w.left2;
+        w.cell += cs;
     }
-    const int lf = is0 ? l0 : (is1 ? l1 : l2);
-    if (lf == 0) return false;                      // Pos[stepAxis] == Out[stepAxis]
-    const float dl = is0 ? d0 : (is1 ? d1 : d2);
-    const int cs = is0 ? c0 : (is1 ? c1 : c2);
-    if (crossed_t) *crossed_t = nx_t;
-    const float nn = nx_t + dl;
-    w.next0 = is0 ? nn : n0;
-    w.next1 = is1 ? nn : n1;
-    w.next2 = is2 ? nn : n2;
-    w.left0 = is0 ? lf - 1 : l0;
-    w.left1 = is1 ? lf - 1 : l1;
-    w.left2 = is2 ? lf - 1 : l2;
-    w.cell += cs;
-    return true;
+    return go;
 }
 
 // Occupancy bitmap of the grid into LDS, all loads of a thread in flight together (16 bytes each).
