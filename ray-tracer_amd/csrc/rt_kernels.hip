@@ -796,7 +796,7 @@ __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t
     const bool c01 = n0 < n1, c02 = n0 < n2, c12 = n1 < n2;
     const bool is0 = c01 && c02;
     const bool is1 = !c01 && c12;
-    const bool is2 = !(is0 || is1);
+    const bool is01 = is0 || is1;                   // else axis 2
     const float nx_t = is0 ? n0 : (is1 ? n1 : n2);
     const int lf = is0 ? w.left0 : (is1 ? w.left1 : w.left2);
     // the ray is done when it has a hit nearer than the next voxel (early exit) or stands in the last voxel of the
@@ -810,10 +810,10 @@ __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t
         const float nn = nx_t + dl;
         w.next0 = is0 ? nn : n0;
         w.next1 = is1 ? nn : n1;
-        w.next2 = is2 ? nn : n2;
+        w.next2 = is01 ? n2 : nn;
         w.left0 = is0 ? lf - 1 : w.left0;
         w.left1 = is1 ? lf - 1 : w.left1;
-        w.left2 = is2 ? lf - 1 : w.left2;
+        w.left2 = is01 ? w.left2 : lf - 1;
         w.cell += cs;
     }
     return go;
