@@ -509,7 +509,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.count_work = s->count_work ? 1 : 0;
     f.unit_shifts = s->sched_shifts;
     f.adapt_units = s->sched_adapt ? 1 : 0;
-    { const char* e = getenv("RT_CULL_MIN"); const char* e2 = getenv("RT_CULL_LANE_RUNS"); f.cull_min = (e ? atoi(e) : 96) | ((e2 ? atoi(e2) : 12) << 16); }
+    { const char* e = getenv("RT_CULL_MIN"); const char* e2 = getenv("RT_CULL_LANE_RUNS"); f.cull_min = (e ? atoi(e) : 64) | ((e2 ? atoi(e2) : 12) << 16); }
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;
