@@ -141,10 +141,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
+    # RT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: the ranks share the visible GPUs
+    # and the gather is staged through host memory. Its numbers mean nothing; it exercises the N > 1 code path.
+    rehearsal = os.environ.get("RT_BENCH_BACKEND", "nccl") == "gloo"
+    if rehearsal:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     rt = importlib.import_module("ray-tracer_amd")
     scene, pkw, W, H, label = build_workload(rt, args.workload)
@@ -161,7 +169,13 @@ def main():
     def step():
         scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_u8.data_ptr(), stream=stream)
         if world > 1:
-            gather_parts(part_u8, world, rank, out=gathered)
+            if rehearsal:
+                torch.cuda.synchronize()
+                g = gather_parts(part_u8.cpu(), world, rank)
+                if rank == 0:
+                    gathered.copy_(g)
+            else:
+                gather_parts(part_u8, world, rank, out=gathered)
             if rank == 0:
                 rt.deinterleave_device(p, gathered.data_ptr(), frame_u8.data_ptr(), 3, stream=stream)
 
@@ -192,6 +206,16 @@ def main():
     ms_build = float(np.mean([x["ms_build"] for x in st]))
     hits_local = st[0]["hits"]
     rays_local = st[0]["primary_rays"] + hits_local
+
+    # N > 1: the gathered, de-interleaved frame must be the frame one GPU renders alone (untimed check on rank 0)
+    frame_check = None
+    if world > 1 and rank == 0:
+        p1 = rt.default_params(W, H, walk_mode=walk, part_index=0, part_count=1, **pkw)
+        single = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        scene.render_device(p1, rebuild_grid=False, d_u8=single.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        frame_check = bool(torch.equal(single, frame_u8))
+        del single
 
     # one extra, untimed frame with the counting kernel: voxel steps and triangle tests actually needed
     scene.set_counting(True)
@@ -232,6 +256,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "strong",
+            "frame_check": frame_check,
             "vs_baseline": None,
             "dtype": "f32+f64",
             "data": "synthetic" if "STAND-IN" in label or "plane" in label else "reference meshes",
