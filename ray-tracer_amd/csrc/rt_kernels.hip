@@ -485,6 +485,22 @@ __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
 
 __device__ __forceinline__ float bcast_f32(float v, int src_lane);
 
+// Wavefront reductions without LDS traffic: four steps inside every row of 16 lanes on the data-parallel-primitive path
+// of the vector ALU (lane pairs 1 apart, 2 apart, mirrored in 8, mirrored in 16), then the four row results are read
+// through scalar registers. The result is the same in every lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <typename Op>
+__device__ __forceinline__ float wave_reduce_f32(float v, Op op) {
+    v = op(v, dpp_f32<0xB1>(v));        // quad_perm [1,0,3,2]
+    v = op(v, dpp_f32<0x4E>(v));        // quad_perm [2,3,0,1]
+    v = op(v, dpp_f32<0x141>(v));       // row_half_mirror
+    v = op(v, dpp_f32<0x140>(v));       // row_mirror
+    return op(op(bcast_f32(v, 0), bcast_f32(v, 16)), op(bcast_f32(v, 32), bcast_f32(v, 48)));
+}
+
 // BLOCK BOUNDS of every aligned run of 64 records: the axis-aligned box of its triangles (lo.xyz + largest absolute
 // coordinate, hi.xyz) and a slab: a unit vector n (the run's summed triangle normals; consecutive triangles of a mesh
 // form a nearly flat patch) with the smallest and largest n.v over the run's vertices. All triangles of the run lie
@@ -524,16 +540,12 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
             const float fx = bcast_f32(nx, 0), fy = bcast_f32(ny, 0), fz = bcast_f32(nz, 0);
             if (nx * fx + ny * fy + nz * fz < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
         }
+        auto f_min = [](float a, float c) { return fminf(a, c); };
+        auto f_max = [](float a, float c) { return fmaxf(a, c); };
+        auto f_add = [](float a, float c) { return a + c; };
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
-                hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { nx += __shfl_xor(nx, off); ny += __shfl_xor(ny, off); nz += __shfl_xor(nz, off); }
+        for (int a = 0; a < 3; ++a) { lo[a] = wave_reduce_f32(lo[a], f_min); hi[a] = wave_reduce_f32(hi[a], f_max); }
+        nx = wave_reduce_f32(nx, f_add); ny = wave_reduce_f32(ny, f_add); nz = wave_reduce_f32(nz, f_add);
         {
             const float len = sqrtf(nx * nx + ny * ny + nz * nz);
             if (len > 1e-30f && len < 1e30f) { nx /= len; ny /= len; nz /= len; } else { nx = 0.f; ny = 0.f; nz = 0.f; }
@@ -546,8 +558,7 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
                 dmin = fminf(dmin, d); dmax = fmaxf(dmax, d);
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { dmin = fminf(dmin, __shfl_xor(dmin, off)); dmax = fmaxf(dmax, __shfl_xor(dmax, off)); }
+        dmin = wave_reduce_f32(dmin, f_min); dmax = wave_reduce_f32(dmax, f_max);
         if (lane == 0) {
             float m = 0.f;
 #pragma unroll
