@@ -1,5 +1,7 @@
 """GPU: the HIP path, called through the C ABI, against the golden vectors and the oracle.
 Bars: hit ids bit-exact; float colours within 1/255 on >= 99.9 % of pixels (measured: bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -338,3 +340,28 @@ def test_mesh_far_from_the_origin(rt, O):
     assert (o_ids >= 0).sum() > 1000
     rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL, **kw))
     check_image(rgb, ids, o_rgb, o_ids)
+
+
+REFERENCE_TEST_PPM_MD5 = "6d0132d9012a63a6dbad30557dfcf757"     # ./test.ppm of the compiled Serial/raytracer.cpp (any -O level)
+
+
+def test_render_ppm_is_the_reference_binarys_file(rt, tmp_path):
+    """render() of Serial/raytracer.cpp:120-187 including its file output: same bytes as the reference's test.ppm."""
+    import hashlib
+    s = rt.Scene(); s.load_mesh(SPOT); s.load_mesh(BLUB, True, (255, 0, 0), (1.5, 0, 0))
+    out = tmp_path / "test.ppm"
+    s.render_ppm(rt.default_params(), str(out))
+    assert hashlib.md5(out.read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
+
+
+def test_command_line_program_is_a_drop_in_for_main(tmp_path):
+    """The built CLI with no arguments in a directory holding the two meshes does what the reference's main() does
+    (Serial/raytracer.cpp:191-200) and leaves the same ./test.ppm."""
+    import hashlib, shutil, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "ray-tracer_amd", "rt")
+    assert os.path.exists(exe), "ray-tracer_amd/rt has not been built (make -C ray-tracer_amd/csrc)"
+    shutil.copy(SPOT, tmp_path / "spot_triangulated.obj")
+    shutil.copy(BLUB, tmp_path / "blub_triangulated.obj")
+    subprocess.run([exe], cwd=tmp_path, check=True, timeout=100)
+    assert hashlib.md5((tmp_path / "test.ppm").read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
