@@ -365,3 +365,30 @@ def test_command_line_program_is_a_drop_in_for_main(tmp_path):
     shutil.copy(BLUB, tmp_path / "blub_triangulated.obj")
     subprocess.run([exe], cwd=tmp_path, check=True, timeout=100)
     assert hashlib.md5((tmp_path / "test.ppm").read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
+
+
+def test_unit_diagnostics_are_consistent(rt):
+    """rt_scene_unit_costs after a counting frame: one record per work unit, and the per-unit numbers add up to the
+    per-tile and per-frame ones (layout in include/rt_amd.h)."""
+    s = rt.Scene(); s.load_mesh(SPOT); s.load_mesh(BLUB, True, (255, 0, 0), (1.5, 0, 0))
+    W, H = 256, 192
+    p = rt.default_params(W, H)
+    s.set_counting(True)
+    rgb, _, ids = s.render(p)
+    st = s.last_stats()
+    s.set_counting(False)
+    t = ((W + 7) // 8) * ((H + 7) // 8)
+    c = s.unit_costs(112 * t)
+    assert len(c) == 112 * t
+    unit_cyc, tile_cyc = c[:16 * t].astype(np.int64), c[20 * t:21 * t].astype(np.int64)
+    info, work = c[21 * t:37 * t], c[37 * t:53 * t]
+    used = unit_cyc > 0
+    assert used.sum() == st["tiles_traced"]                     # work units of the frame
+    assert unit_cyc.sum() == tile_cyc.sum() == st["tile_cycles_sum"]
+    assert int((work[used] & 0x3ffff).sum()) == st["run_ray_trips"]
+    assert int((work[used] >> 18).sum()) == st["runs_streamed"]
+    tiles = info[used] & 0xffffff
+    assert tiles.max() < t and (tile_cyc[np.unique(tiles)] > 0).all()
+    # the counting frame renders the same image
+    rgb2, _, ids2 = s.render(p)
+    assert np.array_equal(ids, ids2) and np.array_equal(bits(rgb), bits(rgb2))
