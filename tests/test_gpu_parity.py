@@ -392,3 +392,26 @@ def test_unit_diagnostics_are_consistent(rt):
     # the counting frame renders the same image
     rgb2, _, ids2 = s.render(p)
     assert np.array_equal(ids, ids2) and np.array_equal(bits(rgb), bits(rgb2))
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_views_of_a_crowded_scene(rt, O, seed):
+    """Random cameras, lights and frame sizes on spot + the blub mesh subdivided twice (227,328 triangles, voxels with
+    hundreds of references: run culling and the shared-reciprocal divisions are at work), against the oracle."""
+    rng = np.random.default_rng(seed)
+    tmp = rt.Scene(); tmp.load_mesh(BLUB); v9 = rt.subdivide(tmp.triangles(), 2).copy(); tmp.close()
+    v9[:, 0::3] += 1.5
+    s = rt.Scene(); s.load_mesh(SPOT); s.add_triangles(v9, (30, 200, 90))
+    o = O.OracleScene(); o.add_obj(SPOT); o.add_triangles(v9, (30, 200, 90))
+    for _ in range(4):
+        r, th, ph = rng.uniform(0.3, 10.0), rng.uniform(0, 2 * np.pi), rng.uniform(-1.2, 1.2)
+        kw = dict(cam_pos=(float(0.75 + r * np.cos(th) * np.cos(ph)), float(r * np.sin(ph)), float(r * np.sin(th) * np.cos(ph))),
+                  cam_target=(float(rng.uniform(-0.5, 2.0)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5))),
+                  fov=float(rng.uniform(5, 110)), light_pos=tuple(float(x) for x in rng.uniform(-8, 8, 3)))
+        W, H = int(rng.integers(17, 300)), int(rng.integers(9, 200))
+        o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0, **kw))
+        rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL, **kw))
+        check_image(rgb, ids, o_rgb, o_ids)
+        rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_EARLY, **kw))
+        n_id, _ = check_image(rgb, ids, o_rgb, o_ids, exact=False)
+        assert n_id <= 2

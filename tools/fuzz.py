@@ -1,4 +1,4 @@
-"""Random views of the reference's scene against the oracle (GPU + CPU oracle): python tools/fuzz.py [n_views] [seed]"""
+"""Random views of the reference's scene against the oracle (GPU + CPU oracle): python tools/fuzz.py [n_views] [seed] [subdivisions]"""
 import importlib, sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,8 +9,14 @@ MESH = os.path.join(ROOT, "tests", "golden", "meshes")
 SPOT, BLUB = os.path.join(MESH, "spot_triangulated.obj"), os.path.join(MESH, "blub_triangulated.obj")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-s = rt.Scene(); s.load_mesh(SPOT); s.load_mesh(BLUB, True, (30, 200, 90), (1.5, 0, 0))
-o = O.OracleScene(); o.add_obj(SPOT); o.add_obj(BLUB, True, (30, 200, 90), (1.5, 0, 0))
+s = rt.Scene(); o = O.OracleScene()
+if len(sys.argv) > 3:       # third argument k: the blub mesh subdivided k times (crowded voxels), beside spot
+    tmp = rt.Scene(); tmp.load_mesh(BLUB); v9 = rt.subdivide(tmp.triangles(), int(sys.argv[3])); tmp.close()
+    v9 = v9.copy(); v9[:, 0::3] += 1.5
+    s.load_mesh(SPOT); s.add_triangles(v9, (30, 200, 90)); o.add_obj(SPOT); o.add_triangles(v9, (30, 200, 90))
+else:
+    s.load_mesh(SPOT); s.load_mesh(BLUB, True, (30, 200, 90), (1.5, 0, 0))
+    o.add_obj(SPOT); o.add_obj(BLUB, True, (30, 200, 90), (1.5, 0, 0))
 bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
 bad = 0
 for k in range(n):
