@@ -220,6 +220,26 @@ __global__ void __launch_bounds__(256) k_count(RtBuildDev b) {
     }
 }
 
+// COUNT for small meshes: one WAVEFRONT per triangle, the lanes share out the voxels of its range. With a few thousand
+// triangles the thread-per-triangle kernel above is a handful of wavefronts whose run time is the largest triangle's
+// voxel count times a round of pooling; here the number of atomics is small anyway and a large triangle costs a few trips.
+#define RT_WIDE_MAX_TRIS 65536u
+__global__ void __launch_bounds__(256) k_count_wide(RtBuildDev b) {
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= b.n_tris) return;
+    const RtGrid g = *b.grid;
+    int vmin[3], vmax[3];
+    tri_voxel_range(b, g, i, vmin, vmax);
+    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1, exy = ex * ey;
+    const int n = exy * (vmax[2] - vmin[2] + 1);
+    for (int r = lane; r < n; r += 64) {
+        const int z = r / exy, q = r - z * exy, y = q / ex, x = q - y * ex;
+        atomicAdd(&b.cell_count[(vmin[2] + z) * nxy + (vmin[1] + y) * nx + (vmin[0] + x)], 1u);
+    }
+}
+
 // SCAN part 1: per-chunk totals. A chunk is RT_SCAN_CHUNK consecutive cells, one 256-thread block each.
 __global__ void k_scan_sums(RtBuildDev b) {
     __shared__ uint32_t wsum[4];
@@ -323,6 +343,26 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
     }
 }
 
+// SCATTER for small meshes, one wavefront per triangle like k_count_wide.
+__global__ void __launch_bounds__(256) k_scatter_wide(RtBuildDev b) {
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const RtGrid g = *b.grid;
+    if (g.n_refs > b.ref_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) b.grid->overflow = 1; return; }
+    if (i >= b.n_tris) return;
+    int vmin[3], vmax[3];
+    tri_voxel_range(b, g, i, vmin, vmax);
+    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1, exy = ex * ey;
+    const int n = exy * (vmax[2] - vmin[2] + 1);
+    for (int r = lane; r < n; r += 64) {
+        const int z = r / exy, q = r - z * exy, y = q / ex, x = q - y * ex;
+        const int c = (vmin[2] + z) * nxy + (vmin[1] + y) * nx + (vmin[0] + x);
+        const uint32_t pos = b.cell_start[c] + atomicSub(&b.cell_count[c], 1u) - 1u;
+        b.ref_tri[pos] = i;
+        b.ref_cell[pos] = (uint32_t)c;
+    }
+}
 
 // ROW SORT: every aligned row of 64 references is sorted by (voxel, triangle index) inside its wavefront (bitonic
 // network over the lanes). References are already grouped by voxel, so a voxel's references keep their places in the
@@ -577,7 +617,8 @@ hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st) {
         k_bounds<<<nb < 256 ? nb : 256, 256, 0, st>>>(b);
     }
     k_grid_setup<<<1, 64, 0, st>>>(b);
-    if (b.n_tris) k_count<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
+    if (b.n_tris && b.n_tris <= RT_WIDE_MAX_TRIS) k_count_wide<<<(b.n_tris + 3) / 4, 256, 0, st>>>(b);
+    else if (b.n_tris) k_count<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
     k_scan_sums<<<RT_MAX_SCAN_BLOCKS, 256, 0, st>>>(b);
     k_scan_apply<<<RT_MAX_SCAN_BLOCKS, 256, 0, st>>>(b);
     return hipGetLastError();
@@ -585,7 +626,8 @@ hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st) {
 
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st) {
     if (b.n_tris == 0) return hipSuccess;
-    k_scatter<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
+    if (b.n_tris <= RT_WIDE_MAX_TRIS) k_scatter_wide<<<(b.n_tris + 3) / 4, 256, 0, st>>>(b);
+    else k_scatter<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
     k_row_sort<<<1024, 256, 0, st>>>(b);
     k_order_emit<<<2048, 256, 0, st>>>(b);
     k_block_bounds<<<1024, 256, 0, st>>>(b);
@@ -879,15 +921,15 @@ __device__ __forceinline__ void estimate_walk(const RtSceneDev& s, const GridU& 
     }
     const uint32_t kept = met < RT_EST_CELLS ? met : RT_EST_CELLS;
     uint32_t c = 0;
-    for (uint32_t k = 0; k < kept; k += 4) {
-        uint32_t lo[4], hi[4];
+    for (uint32_t k = 0; k < kept; k += 8) {           // sixteen loads in flight: the kernel is a chain of round trips
+        uint32_t lo[8], hi[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             const uint32_t cell = cells[((k + j < kept) ? k + j : k) * 256 + threadIdx.x];
             lo[j] = s.cell_start[cell]; hi[j] = s.cell_start[cell + 1];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (k + j < kept) c += hi[j] - lo[j];
+        for (int j = 0; j < 8; ++j) if (k + j < kept) c += hi[j] - lo[j];
     }
     if (met > kept) c = (uint32_t)((unsigned long long)c * met / kept);
     tris = c; voxels = met;
