@@ -755,8 +755,8 @@ __device__ __forceinline__ void write_pixel(const RtFrame& f, const RtOutputs& o
 // work[0] = number of listed tiles, work[1] = dequeue head; both zeroed by the host before each frame.
 // Runs over the tile rectangle [tx0, tx0+ntx) x [tb0, tb0+ntb) (tile columns x local bands) that can contain rays
 // entering the grid; the host has cleared the outputs to the background, so tiles that are not listed need no write.
-#define RT_CLS_TILES_PER_WAVE 4
-
+// tiles per wavefront: 16 on large frames (fewer atomics), 4 on small ones (shorter chains per wavefront)
+template <int RT_CLS_TILES_PER_WAVE>
 __global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, RtFrame f, uint32_t* work, uint32_t* tile_list, int tx0,
                                                   int ntx, int tb0, int ntb) {
     __shared__ uint32_t wave_cnt[4];
@@ -764,27 +764,49 @@ __global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, Rt
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tiles_x = (f.width + RT_TILE - 1) / RT_TILE;
     const GridU g = load_grid(s.grid);
-    // every wavefront tests RT_CLS_TILES_PER_WAVE tiles; the tiles to list are appended with ONE atomic per block
-    // (a single counter takes only some tens of atomics per microsecond)
-    int mine[RT_CLS_TILES_PER_WAVE];
-    uint32_t n_mine = 0;
-#pragma unroll
-    for (int k = 0; k < RT_CLS_TILES_PER_WAVE; ++k) {
-        const int t = (blockIdx.x * 4 + wv) * RT_CLS_TILES_PER_WAVE + k;
-        mine[k] = -1;
-        if (t < ntx * ntb) {
-            const int tile = (tb0 + t / ntx) * tiles_x + tx0 + t % ntx;
+    // Every wavefront looks at RT_CLS_TILES_PER_WAVE tiles; the tiles to list are appended with ONE atomic per block (a
+    // single counter takes about a hundred atomics per microsecond: with few tiles per block the kernel is that long).
+    // First the four corner pixels of all its tiles at once (lane = tile * 4 + corner): one ray that enters settles
+    // a tile, and on frames the geometry fills that is nearly every tile. Only tiles none of whose corners enters get the
+    // test of all 64 rays.
+    const int first = (blockIdx.x * 4 + wv) * RT_CLS_TILES_PER_WAVE;
+    const int n_cls = ntx * ntb;
+    auto tile_of = [&](int t) { return (tb0 + t / ntx) * tiles_x + tx0 + t % ntx; };
+    unsigned long long corner_hits;
+    {
+        const int t = first + (lane >> 2), corner = lane & 3;
+        bool enters = false;
+        if (lane < 4 * RT_CLS_TILES_PER_WAVE && t < n_cls) {
             int x, y_local, y;
-            tile_pixel(f, tile, lane, x, y_local, y);
+            tile_pixel(f, tile_of(t), (corner & 1 ? 7 : 0) + (corner & 2 ? 56 : 0), x, y_local, y);
+            // partial tiles at the frame's edges: the last pixel inside the frame is their corner
+            if (x >= f.width) x = f.width - 1;
+            if (y >= f.height) y = (y - (corner & 2 ? 7 : 0) < f.height) ? f.height - 1 : -1;     // -1: the tile lies below the frame
+            if (y >= 0) {
+                float dx, dy, dz, rayT;
+                primary_ray(cam, f, x, y, dx, dy, dz);
+                enters = grid_entry(g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, rayT);
+            }
+        }
+        corner_hits = __ballot(enters);
+    }
+    uint32_t listed = 0;                       // bit k: tile first + k is listed (the same in every lane)
+    for (int k = 0; k < RT_CLS_TILES_PER_WAVE && first + k < n_cls; ++k) {
+        bool any = ((corner_hits >> (4 * k)) & 0xfull) != 0ull;
+        if (!any) {
+            int x, y_local, y;
+            tile_pixel(f, tile_of(first + k), lane, x, y_local, y);
             bool enters = false;
             if (x < f.width && y < f.height) {
                 float dx, dy, dz, rayT;
                 primary_ray(cam, f, x, y, dx, dy, dz);
                 enters = grid_entry(g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, rayT);
             }
-            if (__ballot(enters)) { mine[k] = tile; ++n_mine; }
+            any = __ballot(enters) != 0ull;
         }
+        if (any) listed |= 1u << k;
     }
+    const uint32_t n_mine = (uint32_t)__popc(listed);
     if (lane == 0) wave_cnt[wv] = n_mine;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -792,12 +814,10 @@ __global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, Rt
         block_base = total ? atomicAdd(&work[0], total) : 0u;
     }
     __syncthreads();
-    if (lane == 0 && n_mine) {
+    if (lane < RT_CLS_TILES_PER_WAVE && ((listed >> lane) & 1u)) {
         uint32_t pos = block_base;
         for (int k = 0; k < wv; ++k) pos += wave_cnt[k];
-#pragma unroll
-        for (int k = 0; k < RT_CLS_TILES_PER_WAVE; ++k)
-            if (mine[k] >= 0) tile_list[pos++] = (uint32_t)mine[k];
+        tile_list[pos + (uint32_t)__popc(listed & ((1u << lane) - 1u))] = (uint32_t)tile_of(first + lane);
     }
 }
 
@@ -1653,7 +1673,8 @@ static int trace_blocks(const RtFrame& f, const RtRenderWork& wk) {
 hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtRenderWork wk, hipStream_t st) {
     const int n_cls = wk.ntx * wk.ntb;
     if (n_cls <= 0 || s.n_tris == 0) return hipSuccess;
-    k_classify<<<(n_cls + 4 * RT_CLS_TILES_PER_WAVE - 1) / (4 * RT_CLS_TILES_PER_WAVE), 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
+    if (n_cls > 16384) k_classify<16><<<(n_cls + 63) / 64, 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
+    else k_classify<4><<<(n_cls + 15) / 16, 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
     const int nb = (n_cls + 255) / 256;
     k_estimate<<<(n_cls + 63) / 64, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles,
                                                                                         make_float4(wk.est_w[0], wk.est_w[1], wk.est_w[2], wk.est_w[3]));
