@@ -9,6 +9,7 @@
 #define RT_SCAN_CHUNK 1024                         // cells per scan block
 #define RT_MAX_SCAN_BLOCKS (RT_MAX_CELLS / RT_SCAN_CHUNK)
 #define RT_WORK_LIST_COUNTS 32                     // first work[] word of the per-list tile counts (128 bytes after the head)
+#define RT_COST_SUM_PARTS 32u                       // partial sums of the cost estimate (power of two)
 #define RT_QUEUE_LISTS 16                          // tile lists the trace kernel serves in order (cost classes)
 
 // Grid description, resident in device memory: k_grid_setup writes the geometry, k_scan_apply writes n_refs.
@@ -79,7 +80,7 @@ struct RtRenderWork {
     uint32_t* est_by_tile;        // diagnostics: the four estimate features, each indexed by tile of the frame (may be NULL)
     int32_t n_tiles;              // tiles of the frame
     float est_w[4];               // estimate weights: primary triangles, primary voxels, shadow triangles, shadow voxels
-    unsigned long long* cost_sum; // zeroed before each frame
+    unsigned long long* cost_sum; // RT_COST_SUM_PARTS partial sums of the tile estimates, zeroed before each frame
     uint32_t* lists;              // RT_QUEUE_LISTS tile lists in queue order, list_cap entries each
     uint32_t list_cap;            // = tiles of the frame
     float thr0, thr1;             // class limits: 1/thr0 and 1/thr1 of a wavefront's even share of the frame's estimate

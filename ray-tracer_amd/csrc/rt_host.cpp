@@ -71,7 +71,7 @@ struct rt_scene {
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
     DevBuf<uint2> row_minmax;
     DevBuf<float4> recs, blk_bounds;
-    DevBuf<unsigned long long> counters;   // 24 frame counters, then the work-list words (RtRenderWork::work)
+    DevBuf<unsigned long long> counters;   // 24 frame counters, the work-list words (RtRenderWork::work, 32 of them), 32 partial sums of the cost estimate
     DevBuf<uint32_t> tile_list, unit_cost, tile_cost, queue_lists;
     int n_cu = 0;
     uint32_t known_cells = 0;              // n_cells of the current triangle list once measured
@@ -337,7 +337,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
-        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(56)))
+        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(88)))
         return rc;
     HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
     HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
@@ -488,7 +488,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         side = s->side_stream;
         HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
     }
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 56 * sizeof(unsigned long long), side));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 88 * sizeof(unsigned long long), side));
     if (s->count_work) HIP_TRY(hipMemsetAsync(s->counters.p + 22, 0xff, sizeof(unsigned long long), side));   // slot of a minimum
 
     RtSceneDev sd;
@@ -544,7 +544,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
             o.unit_cost = s->unit_cost.p; o.tile_cycles = s->unit_cost.p + 20 * tiles; o.unit_info = s->unit_cost.p + 21 * tiles; wk.est_by_tile = s->unit_cost.p + 16 * tiles;
         }
         wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 24);
-        wk.cost_sum = s->counters.p + 20;
+        wk.cost_sum = s->counters.p + 56;          // 32 words behind the work-list words in use (work[0..63])
         if ((rc = s->tile_cost.ensure(tiles ? tiles : 1))) return rc;
         wk.cost = s->tile_cost.p;
         if ((rc = s->queue_lists.ensure((tiles ? tiles : 1) * RT_QUEUE_LISTS))) return rc;

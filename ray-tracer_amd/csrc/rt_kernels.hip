@@ -1001,7 +1001,8 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
     unsigned long long t = c;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-    if ((threadIdx.x & 63) == 0 && t) atomicAdd(cost_sum, t);
+    // 32 partial sums: one address takes only about a hundred atomics per microsecond, and a 4K frame has 8,000 wavefronts here
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(&cost_sum[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (RT_COST_SUM_PARTS - 1u)], t);
 }
 
 // QUEUE ORDER. The listed tiles are spread over RT_QUEUE_LISTS lists that the trace kernel serves one after the other:
@@ -1030,7 +1031,10 @@ __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* 
         }
         work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + threadIdx.x] = sh;
     }
-    const float share = (float)((double)*cost_sum / (double)n_waves);
+    unsigned long long cost_total = 0;
+#pragma unroll 8
+    for (uint32_t k = 0; k < RT_COST_SUM_PARTS; ++k) cost_total += cost_sum[k];
+    const float share = (float)((double)cost_total / (double)n_waves);
     const float lim0 = fmaxf(share / div0, 1.f), lim1 = fmaxf(share / div1, 0.5f);
     int cls = -1;
     uint32_t tile = 0;
