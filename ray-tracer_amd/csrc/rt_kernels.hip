@@ -1052,15 +1052,29 @@ __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* 
             cls = 8 + (q < 0 ? 0 : (q > 3 ? 3 : q));
         }
     }
+    // places in the lists: counted per wavefront (ballots), summed per block in LDS, and ONE atomic per list and block
+    // claims the block's places, the sixteen lists at once
+    __shared__ uint32_t wave_cnt[4][RT_QUEUE_LISTS];
+    __shared__ uint32_t block_base[RT_QUEUE_LISTS];
+    const int wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t my_cnt = 0, my_rank = 0;          // lane k < 16: this wavefront's tiles for list k; every lane: its place among them
     for (int k = 0; k < RT_QUEUE_LISTS; ++k) {
         const unsigned long long m = __ballot(cls == k);
-        if (!m) continue;
-        uint32_t base = 0;
-        const int first = __ffsll((long long)m) - 1;
-        if (lane == first) base = atomicAdd(&work[RT_WORK_LIST_COUNTS + k], (uint32_t)__popcll(m));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-        if (cls == k) lists[(size_t)k * cap + base + (uint32_t)__popcll(m & lt_mask)] = tile;
+        if (lane == k) my_cnt = (uint32_t)__popcll(m);
+        if (cls == k) my_rank = (uint32_t)__popcll(m & lt_mask);
+    }
+    if (lane < RT_QUEUE_LISTS) wave_cnt[wv][lane] = my_cnt;
+    __syncthreads();
+    if (threadIdx.x < RT_QUEUE_LISTS) {
+        const uint32_t total = wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
+        block_base[threadIdx.x] = total ? atomicAdd(&work[RT_WORK_LIST_COUNTS + threadIdx.x], total) : 0u;
+    }
+    __syncthreads();
+    if (cls >= 0) {
+        uint32_t pos = block_base[cls] + my_rank;
+        for (int k = 0; k < wv; ++k) pos += wave_cnt[k][cls];
+        lists[(size_t)cls * cap + pos] = tile;
     }
 }
 
