@@ -1157,6 +1157,14 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 #ifndef RT_STEPS_PER_ROUND
 #define RT_STEPS_PER_ROUND 8
 #endif
+// voxels of up to this many records are tested by the rays standing in them (lane = ray) when at least
+// RT_OWN_MIN_RAYS rays of the wavefront stand in such voxels; 0 switches the path off
+#ifndef RT_OWN_MAX_RECORDS
+#define RT_OWN_MAX_RECORDS 8
+#endif
+#ifndef RT_OWN_MIN_RAYS
+#define RT_OWN_MIN_RAYS 4
+#endif
 
 // GridAccel::Intersect (Serial/grid.h:167-231) for the 64 rays of a wavefront at once. Every lane must call it.
 //   ANY_HIT: the shadow query. The reference ORs every voxel's result over the whole walk and ignores t,
@@ -1303,6 +1311,55 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     u0 |= m0; u1 |= m1;
                 }
                 if (lane == leader) { any0 = u0; any1 = u1; }      // runs some ray of this voxel needs, kept in its first lane
+            }
+        }
+        // ---- OWN: voxels with a handful of records, lane = ray. In a sparse scene the rays of a unit stand in dozens of
+        // different voxels of a few triangles each; streamed as (voxel, run) items every one of them would cost a trip of
+        // the whole wavefront for a handful of busy lanes. Here every such ray reads the records of its own voxel and
+        // tests them itself, in ascending order (the reference's order), with the expressions of the TEST phase.
+        if (RT_OWN_MAX_RECORDS > 0) {
+            const bool own = at_voxel && !cull && (cend - cbeg) <= (uint32_t)RT_OWN_MAX_RECORDS;
+            const unsigned long long om = __ballot(own);
+            if (__popcll(om) >= RT_OWN_MIN_RAYS) {
+                un &= ~om;
+                uint32_t own_tests = 0;
+                if (own) {
+                    for (uint32_t p = cbeg; p < cend; ++p) {
+                        const float4* r = s.recs + 3ull * p;
+                        const TriRec t = unpack_rec(r[0], r[1], r[2]);
+                        if (COUNT) ++own_tests;
+                        const double sx = t.v0x - ox, sy = t.v0y - oy, sz = t.v0z - oz;          // float subtractions, then widened
+                        const double p_e2s = minor_f32(t.e2y, sz, sy, t.e2z);
+                        const double p_e1s = minor_f32(t.e1y, sz, sy, t.e1z);
+                        const double p_e2d = minor_f32(t.e2y, ddz, ddy, t.e2z);
+                        const double p_e1d = minor_f32(t.e1y, ddz, ddy, t.e1z);
+                        const double p_sd = minor_f32(sy, ddz, ddy, sz);
+                        const double A = t.e1x * p_e2d - t.e2x * p_e1d + ddx * t.m12;
+                        const double bnum = sx * p_e2d - t.e2x * p_sd - ddx * p_e2s;
+                        const double gnum = t.e1x * p_sd - sx * p_e1d + ddx * p_e1s;
+                        const int ha = __double2hiint(A), hb = __double2hiint(bnum), hg = __double2hiint(gnum);
+                        if (((ha ^ hb) | (ha ^ hg)) < 0) continue;                               // signs differ: beta or gamma <= 0
+                        if (fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12)) continue;               // beta + gamma >= 1 beyond any rounding
+                        const double beta = bnum / A, gamma = gnum / A;
+                        if (!(beta > 0.0 && gamma > 0.0 && beta + gamma < 1.0)) continue;
+                        hit = true;
+                        if (ANY_HIT) {
+                            alive = false;
+                            if (COUNT) wc.tests -= cend - (p + 1u);                              // tests the reference order skips
+                            break;
+                        }
+                        const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
+                        const double t_p = tnum / A;
+                        if (t_p < (double)st.t) {
+                            if (!use_eps || t_p > (double)eps) { st.t = (float)t_p; st.id = (int)t.id; }
+                        }
+                    }
+                }
+                if (COUNT) {                     // tests executed: a wavefront-wide number like the streamed runs' lanes
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) own_tests += __shfl_xor(own_tests, off);
+                    wc.lanes += own_tests;
+                }
             }
         }
         const long long t2 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
