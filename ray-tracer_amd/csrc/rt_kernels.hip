@@ -1014,7 +1014,8 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
 // Every list has its own unit size (RtFrame::unit_shifts).
 __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* tile_list, const uint32_t* cost,
                                                 const unsigned long long* cost_sum, uint32_t* lists, uint32_t cap,
-                                                float div0, float div1, int n_waves, unsigned long long unit_shifts, int adapt) {
+                                                float div0, float div1, int n_waves, unsigned long long unit_shifts, int adapt,
+                                                const RtGrid* grid) {
     const uint32_t n = work[0];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1022,11 +1023,14 @@ __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* 
     // Unit sizes of the lists, for k_trace. The given sizes suit frames with about one listed tile per wavefront; with
     // more tiles per wavefront there are enough units to balance the load anyway, and larger units are cheaper (the
     // stepping, culling and shading of a unit cost the same for 16 rays as for 64): one size up from 2.5 tiles per
-    // wavefront, two from 10.
+    // wavefront, two from 10. In a sparse grid (fewer than two references per voxel on average) most voxels hold a
+    // handful of triangles that the rays test themselves, lane = ray, at a cost that does not depend on the rays of the
+    // unit at all: there the units of the expensive lists are one size larger as well.
     if (blockIdx.x == 0 && threadIdx.x < RT_QUEUE_LISTS) {
         uint32_t sh = (uint32_t)((unit_shifts >> (4 * threadIdx.x)) & 15ull);
         if (adapt) {
-            const uint32_t up = (2u * n >= 5u * (uint32_t)n_waves ? 1u : 0u) + (n >= 10u * (uint32_t)n_waves ? 1u : 0u);
+            uint32_t up = (2u * n >= 5u * (uint32_t)n_waves ? 1u : 0u) + (n >= 10u * (uint32_t)n_waves ? 1u : 0u);
+            if (threadIdx.x < 8 && grid->n_refs < 2u * grid->n_cells) up += 1u;
             sh = sh > up ? sh - up : 0u;
         }
         work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + threadIdx.x] = sh;
@@ -1754,7 +1758,7 @@ hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame
     k_estimate<<<(n_cls + 63) / 64, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles,
                                                                                         make_float4(wk.est_w[0], wk.est_w[1], wk.est_w[2], wk.est_w[3]));
     k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.lists, wk.list_cap, wk.thr0, wk.thr1, trace_blocks(f, wk) * RT_WAVES_PER_BLOCK,
-                                (unsigned long long)f.unit_shifts, f.adapt_units);
+                                (unsigned long long)f.unit_shifts, f.adapt_units, s.grid);
     return hipGetLastError();
 }
 
