@@ -46,6 +46,8 @@ struct RtFrame {
     uint64_t unit_shifts;         // 4 bits per queue list (list 0 lowest): log2 of the work units a tile of the list is cut into
     int32_t adapt_units;          // 1: k_bucket enlarges the units when the frame lists many tiles per wavefront
     int32_t cull_min;             // voxels with at least this many triangles get the per-run box test
+    int32_t own_path;             // 1 = trace kernel with the lane = ray path for voxels of a few records (0 for grids known to be
+                                  // crowded: the plain kernel needs fewer registers)
 };
 
 // Device pointers of one scene.

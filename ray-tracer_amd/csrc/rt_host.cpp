@@ -507,6 +507,10 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.walk_full = (p->walk_mode == RT_WALK_FULL);
     f.early_slack = 0.f;
     f.count_work = s->count_work ? 1 : 0;
+    // A grid has at most RT_MAX_CELLS voxels: from two references per voxel on average it is crowded for certain, and the
+    // trace kernel without the path for voxels of a few records is used (RT_OWN_PATH=0/1 overrides, for experiments).
+    f.own_path = (s->known_refs >= 2u * (uint32_t)RT_MAX_CELLS) ? 0 : 1;
+    if (const char* e = getenv("RT_OWN_PATH")) f.own_path = atoi(e) ? 1 : 0;
     f.unit_shifts = s->sched_shifts;
     f.adapt_units = s->sched_adapt ? 1 : 0;
     { const char* e = getenv("RT_CULL_MIN"); const char* e2 = getenv("RT_CULL_LANE_RUNS"); f.cull_min = (e ? atoi(e) : 64) | ((e2 ? atoi(e2) : 12) << 16); }

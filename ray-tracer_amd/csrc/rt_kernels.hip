@@ -1166,6 +1166,10 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 #ifndef RT_OWN_MAX_RECORDS
 #define RT_OWN_MAX_RECORDS 8
 #endif
+// the same limit for units of 32 rays or fewer, where the idle lanes share the records of a voxel out
+#ifndef RT_OWN_MAX_RECORDS_SHARED
+#define RT_OWN_MAX_RECORDS_SHARED 24
+#endif
 #ifndef RT_OWN_MIN_RAYS
 #define RT_OWN_MIN_RAYS 4
 #endif
@@ -1202,10 +1206,10 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 //   gnum  = e1.x*P(s,d)  -  s.x*P(e1,d) + d.x*P(e1,s)
 // The divisions are only executed when the signs allow beta > 0 and gamma > 0 and the numerators allow
 // beta + gamma < 1 with a 1e-12 relative margin; inside that margin the reference's own expression decides.
-template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT>
+template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT, bool OWN>
 __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* bitmap, int lane, bool active, float ox,
                                           float oy, float oz, float dx, float dy, float dz, float mint, bool use_eps, float eps,
-                                          bool early, float slack, uint32_t cull_min, Nearest& st, WalkCount& wc) {
+                                          bool early, float slack, uint32_t cull_min, int ray_lanes, Nearest& st, WalkCount& wc) {
     Dda w;
     bool alive = false;
     if (__ballot(active)) {
@@ -1321,13 +1325,80 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // different voxels of a few triangles each; streamed as (voxel, run) items every one of them would cost a trip of
         // the whole wavefront for a handful of busy lanes. Here every such ray reads the records of its own voxel and
         // tests them itself, in ascending order (the reference's order), with the expressions of the TEST phase.
-        if (RT_OWN_MAX_RECORDS > 0) {
-            const bool own = at_voxel && !cull && (cend - cbeg) <= (uint32_t)RT_OWN_MAX_RECORDS;
+        if (OWN && RT_OWN_MAX_RECORDS > 0) {
+            const bool own = at_voxel && !cull && (cend - cbeg) <= (uint32_t)(ray_lanes <= 32 ? RT_OWN_MAX_RECORDS_SHARED : RT_OWN_MAX_RECORDS);
             const unsigned long long om = __ballot(own);
             if (__popcll(om) >= RT_OWN_MIN_RAYS) {
                 un &= ~om;
                 uint32_t own_tests = 0;
-                if (own) {
+                if (ray_lanes <= 32) {
+                    // A unit of 32 rays or fewer leaves lanes without a ray: lane g * ray_lanes + r helps ray r and takes
+                    // every G-th record of its voxel (G = 2 or 4 lanes per ray). The passing triangles of a step are then
+                    // applied by the ray's own lane in ascending record order, which is the reference's order.
+                    const int lg = __ffs(ray_lanes) - 1;
+                    const int G = ray_lanes <= 16 ? 4 : 2;
+                    const int r = lane & (ray_lanes - 1), g = lane >> lg;
+                    const bool helper = g < G;
+                    bool own_r = __shfl((int)own, r) != 0 && helper;
+                    const uint32_t cb = (uint32_t)__shfl((int)cbeg, r), ce = (uint32_t)__shfl((int)cend, r);
+                    const float rox = SHARED_ORIGIN ? ox : __shfl(ox, r), roy = SHARED_ORIGIN ? oy : __shfl(oy, r), roz = SHARED_ORIGIN ? oz : __shfl(oz, r);
+                    const double rdx = (double)__shfl(dx, r), rdy = (double)__shfl(dy, r), rdz = (double)__shfl(dz, r);
+                    for (uint32_t base = cb; __ballot(own_r && base < ce); base += (uint32_t)G) {
+                        const uint32_t p = base + (uint32_t)g;
+                        int pass_id = -1;                       // record index of a passing triangle
+                        double t_p = 0.0;
+                        if (own_r && p < ce) {
+                            const float4* rr = s.recs + 3ull * p;
+                            const TriRec t = unpack_rec(rr[0], rr[1], rr[2]);
+                            if (COUNT) ++own_tests;
+                            const double sx = t.v0x - rox, sy = t.v0y - roy, sz = t.v0z - roz;       // float subtractions, then widened
+                            const double p_e2s = minor_f32(t.e2y, sz, sy, t.e2z);
+                            const double p_e1s = minor_f32(t.e1y, sz, sy, t.e1z);
+                            const double p_e2d = minor_f32(t.e2y, rdz, rdy, t.e2z);
+                            const double p_e1d = minor_f32(t.e1y, rdz, rdy, t.e1z);
+                            const double p_sd = minor_f32(sy, rdz, rdy, sz);
+                            const double A = t.e1x * p_e2d - t.e2x * p_e1d + rdx * t.m12;
+                            const double bnum = sx * p_e2d - t.e2x * p_sd - rdx * p_e2s;
+                            const double gnum = t.e1x * p_sd - sx * p_e1d + rdx * p_e1s;
+                            const int ha = __double2hiint(A), hb = __double2hiint(bnum), hg = __double2hiint(gnum);
+                            if (((ha ^ hb) | (ha ^ hg)) >= 0 && !(fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12))) {
+                                const double beta = bnum / A, gamma = gnum / A;
+                                if (beta > 0.0 && gamma > 0.0 && beta + gamma < 1.0) {
+                                    pass_id = (int)t.id;
+                                    if (!ANY_HIT) {
+                                        const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
+                                        t_p = tnum / A;
+                                    }
+                                }
+                            }
+                        }
+                        if (__ballot(pass_id >= 0)) {
+                            bool stop = false;
+                            for (int gg = 0; gg < G; ++gg) {
+                                const int src = (gg << lg) + r;
+                                const int id_g = __shfl(pass_id, src);
+                                if (ANY_HIT) {
+                                    if (id_g >= 0 && !stop) {
+                                        stop = true;
+                                        if (g == 0 && own) {
+                                            hit = true; alive = false;
+                                            if (COUNT) wc.tests -= ce - (base + (uint32_t)gg + 1u);   // tests the reference order skips
+                                        }
+                                    }
+                                } else {
+                                    const double t_g = __shfl(t_p, src);
+                                    if (id_g >= 0 && g == 0 && own) {
+                                        hit = true;
+                                        if (t_g < (double)st.t) {
+                                            if (!use_eps || t_g > (double)eps) { st.t = (float)t_g; st.id = id_g; }
+                                        }
+                                    }
+                                }
+                            }
+                            if (ANY_HIT && stop) own_r = false;
+                        }
+                    }
+                } else if (own) {
                     for (uint32_t p = cbeg; p < cend; ++p) {
                         const float4* r = s.recs + 3ull * p;
                         const TriRec t = unpack_rec(r[0], r[1], r[2]);
@@ -1551,7 +1622,7 @@ struct RtTraceArgs {
     uint32_t list_cap;
 };
 
-template <bool COUNT>
+template <bool COUNT, bool OWN>
 __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArgs args_in_kernarg_segment) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -1624,8 +1695,8 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
         WalkCount wp = {}, ws = {};
         const long long t_start = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const unsigned long long rt_start = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        const bool hit = wave_walk<false, true, COUNT>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
-                                                       sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, st, wp);
+        const bool hit = wave_walk<false, true, COUNT, OWN>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
+                                                       sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, per_unit, st, wp);
         float cr = 0.f, cg = 0.f, cb = 0.f;
         float colr = 0.f, colg = 0.f, colb = 0.f;
         float poix = 0.f, poiy = 0.f, poiz = 0.f, sx = 0.f, sy = 0.f, sz = 1.f;
@@ -1663,8 +1734,8 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
             sx = -(sh.light[0] - poix); sy = -(sh.light[1] - poiy); sz = -(sh.light[2] - poiz);
             normalize3(sx, sy, sz);
         }
-        const bool shadowed = wave_walk<true, false, COUNT>(s, bitmap, lane, hit, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
-                                                            true, 0.f, (uint32_t)f.cull_min, st, ws);
+        const bool shadowed = wave_walk<true, false, COUNT, OWN>(s, bitmap, lane, hit, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
+                                                            true, 0.f, (uint32_t)f.cull_min, per_unit, st, ws);
         if (hit) {
             if (shadowed) { cr = cr * sh.shadow_scale; cg = cg * sh.shadow_scale; cb = cb * sh.shadow_scale; }
             cr = cr + colr * sh.ka; cg = cg + colg * sh.ka; cb = cb + colb * sh.ka;
@@ -1769,8 +1840,13 @@ hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, Rt
     RtTraceArgs ta;
     ta.s = s; ta.cam = cam; ta.sh = sh; ta.f = f; ta.o = o; ta.work = wk.work;
     ta.lists = wk.lists; ta.list_cap = wk.list_cap;
-    if (f.count_work) k_trace<true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
-    else k_trace<false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+    if (f.count_work) {
+        if (f.own_path) k_trace<true, true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+        else k_trace<true, false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+    } else {
+        if (f.own_path) k_trace<false, true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+        else k_trace<false, false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+    }
     return hipGetLastError();
 }
 

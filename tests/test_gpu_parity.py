@@ -195,6 +195,24 @@ def test_unit_sizes_and_cost_classes_do_not_change_the_image(rt, plane10, monkey
         s.close()
 
 
+@pytest.mark.parametrize("own", ["0", "1"])
+@pytest.mark.parametrize("shifts", [None, "0000000000000000", "1111111111111111", "3333333333333333"])
+def test_both_trace_kernels_give_the_golden_image(rt, plane10, monkeypatch, own, shifts):
+    """The trace kernel exists with and without the lane = ray path for voxels of a few records (the library picks by
+    the grid's reference count); with it, units of 64 rays test serially and smaller units share a voxel's records
+    among 2 or 4 lanes per ray. Every combination gives the golden ids and colours bit for bit."""
+    monkeypatch.setenv("RT_OWN_PATH", own)
+    if shifts is not None:
+        monkeypatch.setenv("RT_SHIFTS", shifts)
+    for name in ("main_512x512", "spot_640x480", "plane10_480x270"):
+        s, W, H, cam = _scene(rt, name, plane10)
+        p = rt.default_params(W, H, **cam_kwargs(cam))
+        rgb, u8, ids = s.render(p, want_u8=True)
+        g_ids, g_rgb = golden(name)
+        check_image(rgb, ids, g_rgb, g_ids)
+        s.close()
+
+
 def _rows_against_oracle(rt, O, s, o, W, H, row_blocks, walk_mode):
     """Whole frame on the GPU, sampled row blocks on the CPU oracle (full walk, as the reference runs)."""
     rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=walk_mode))
