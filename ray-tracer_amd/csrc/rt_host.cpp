@@ -480,16 +480,28 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     s->built[slot] = false;
     // With a grid build in the frame, everything that only needs the grid's cell table (clearing the outputs, the tile list
     // and its cost classes) runs on a side stream beside the second half of the build and joins before the trace kernel.
+    // The clearing needs nothing of the grid: the side stream does it beside the first half of the build (it starts where
+    // the frame starts on `st`, that is after the frame before).
     const bool rebuild = rebuild_grid || !s->grid_valid;
     hipStream_t side = st;
     if (rebuild) {
-        if ((rc = build_grid_async(s, st, s->ev_fork))) return rc;
-        s->built[slot] = true;
         side = s->side_stream;
-        HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(side, s->ev[slot][0], 0));
     }
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, 88 * sizeof(unsigned long long), side));
     if (s->count_work) HIP_TRY(hipMemsetAsync(s->counters.p + 22, 0xff, sizeof(unsigned long long), side));   // slot of a minimum
+    {
+        // background everywhere first: black, no hit
+        const size_t out_px = (size_t)p->width * (size_t)rt_part_rows(p);
+        if (d_rgb_f32) HIP_TRY(hipMemsetAsync(d_rgb_f32, 0, out_px * 3 * sizeof(float), side));
+        if (d_rgb_u8) HIP_TRY(hipMemsetAsync(d_rgb_u8, 0, out_px * 3, side));
+        if (d_hit_id) HIP_TRY(hipMemsetAsync(d_hit_id, 0xff, out_px * sizeof(int32_t), side));
+    }
+    if (rebuild) {
+        if ((rc = build_grid_async(s, st, s->ev_fork))) return rc;
+        s->built[slot] = true;
+        HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
+    }
 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
@@ -518,11 +530,6 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = s->counters.p;
     o.unit_cost = nullptr; o.tile_cycles = nullptr; o.unit_info = nullptr;
-    // background everywhere first: black, no hit
-    const size_t out_px = (size_t)p->width * (size_t)f.out_rows;
-    if (o.rgb_f32) HIP_TRY(hipMemsetAsync(o.rgb_f32, 0, out_px * 3 * sizeof(float), side));
-    if (o.rgb_u8) HIP_TRY(hipMemsetAsync(o.rgb_u8, 0, out_px * 3, side));
-    if (o.hit_id) HIP_TRY(hipMemsetAsync(o.hit_id, 0xff, out_px * sizeof(int32_t), side));
     const RtCamera cam = make_camera(p);
     RtRenderWork wk;
     wk.est_by_tile = nullptr;
