@@ -115,7 +115,9 @@ struct RtBuildDev {
 
 // Launch wrappers (rt_kernels.hip). All asynchronous on `st`; they return the hipGetLastError() of their launches.
 hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh, RtBuildDev b, hipStream_t st);
-hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st);   // init, bounds, setup, count, scan -> grid.n_refs known
+// bounds + set-up, count, scan -> grid.n_refs known. `first`: the scene's build state has not been left behind clean by a
+// completed build (k_build_init runs)
+hipError_t rt_launch_build_phase1(RtBuildDev b, bool first, hipStream_t st);
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st);   // scatter, per-cell order, record emit
 hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtRenderWork wk, hipStream_t st);   // classify, estimate, cost classes
 hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st);

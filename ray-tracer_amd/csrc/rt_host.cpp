@@ -64,6 +64,7 @@ struct rt_scene {
     bool grid_valid = false;
     uint32_t known_refs = 0;           // reference count of the current triangle list once measured
     bool refs_known = false;
+    bool build_clean = false;          // the last grid build ran to its end and left its counters reset for the next one
     DevBuf<float4> v0, v1, v2, tri_rec;
     DevBuf<float2> tri_box;
     DevBuf<float> d_mesh_color;
@@ -131,7 +132,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     delete s;
 }
 
-static void scene_touch(rt_scene* s) { s->uploaded = false; s->grid_valid = false; s->refs_known = false; }
+static void scene_touch(rt_scene* s) { s->uploaded = false; s->grid_valid = false; s->refs_known = false; s->build_clean = false; }
 
 extern "C" int64_t rt_scene_add_triangles(rt_scene* s, const float* v9, int64_t n, const float color[3]) {
     if (!s || n < 0 || (n > 0 && !v9) || !color) return set_err(RT_ERR_INVALID, "rt_scene_add_triangles: bad argument");
@@ -358,16 +359,19 @@ extern "C" int rt_scene_upload(rt_scene* s) {
         HIP_TRY(hipMemcpy(s->d_mesh_color.p, s->mesh_color.data(), s->mesh_color.size() * sizeof(float), hipMemcpyHostToDevice));
     s->uploaded = true;
     s->grid_valid = false;
+    s->build_clean = false;
     return RT_OK;
 }
 
 // `after_phase1`, when given, is recorded once cell_start and the occupancy bitmap are final (the records are not yet).
 static int build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_phase1 = nullptr) {
     int rc;
+    const bool first = !s->build_clean;
+    s->build_clean = false;
     if (!s->refs_known) {
         // First build of this triangle list: run count + scan, read the reference total back once and size
         // the reference arrays from it. Later builds of the same list are fully asynchronous.
-        HIP_TRY(rt_launch_build_phase1(build_args(s), st));
+        HIP_TRY(rt_launch_build_phase1(build_args(s), first, st));
         RtGrid g;
         HIP_TRY(hipMemcpyAsync(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -378,11 +382,12 @@ static int build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_phase1
         size_t need = g.n_refs ? g.n_refs : 1;
         if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)) || (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(3 * (need / 64 + 2)))) return rc;
     } else {
-        HIP_TRY(rt_launch_build_phase1(build_args(s), st));
+        HIP_TRY(rt_launch_build_phase1(build_args(s), first, st));
     }
     if (after_phase1) HIP_TRY(hipEventRecord(after_phase1, st));
     HIP_TRY(rt_launch_build_phase2(build_args(s), st));
     s->grid_valid = true;
+    s->build_clean = true;
     return RT_OK;
 }
 
@@ -482,11 +487,19 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     // and its cost classes) runs on a side stream beside the second half of the build and joins before the trace kernel.
     // The clearing needs nothing of the grid: the side stream does it beside the first half of the build (it starts where
     // the frame starts on `st`, that is after the frame before).
+    // Small meshes only: their frame waits for the side stream, while the build of a large mesh is the longer branch and
+    // its bounds kernel runs at half speed beside a 25 MB memset.
     const bool rebuild = rebuild_grid || !s->grid_valid;
+    const bool clear_early = rebuild && s->tri_mesh.size() <= 65536;
     hipStream_t side = st;
     if (rebuild) {
         side = s->side_stream;
-        HIP_TRY(hipStreamWaitEvent(side, s->ev[slot][0], 0));
+        if (clear_early) HIP_TRY(hipStreamWaitEvent(side, s->ev[slot][0], 0));
+        else {
+            if ((rc = build_grid_async(s, st, s->ev_fork))) return rc;
+            s->built[slot] = true;
+            HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
+        }
     }
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, 88 * sizeof(unsigned long long), side));
     if (s->count_work) HIP_TRY(hipMemsetAsync(s->counters.p + 22, 0xff, sizeof(unsigned long long), side));   // slot of a minimum
@@ -497,7 +510,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         if (d_rgb_u8) HIP_TRY(hipMemsetAsync(d_rgb_u8, 0, out_px * 3, side));
         if (d_hit_id) HIP_TRY(hipMemsetAsync(d_hit_id, 0xff, out_px * sizeof(int32_t), side));
     }
-    if (rebuild) {
+    if (clear_early) {
         if ((rc = build_grid_async(s, st, s->ev_fork))) return rc;
         s->built[slot] = true;
         HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));

@@ -92,11 +92,20 @@ __global__ void k_build_init(RtBuildDev b) {
     for (uint32_t c = i; c < RT_MAX_CELLS; c += stride) b.cell_count[c] = 0;
     if (i < 3) b.bounds_enc[i] = 0xff800000u;        // running minimum starts at enc(+inf)
     else if (i < 6) b.bounds_enc[i] = 0x007fffffu;   // running maximum starts at enc(-inf)
-    if (i == 6) { b.grid->n_refs = 0; b.grid->overflow = 0; }
+    if (i == 6) { b.grid->n_refs = 0; b.grid->overflow = 0; b.bounds_enc[6] = 0; }
 }
+
+// State the build kernels leave behind for the next build of the scene, so that k_build_init only has to run before the
+// first one: k_scatter counts cell_count back down to zero (and clears it when it has to give up), grid_setup resets the
+// running bounds, the block counter of k_bounds and the overflow flag, and k_scan_apply always writes n_refs.
+
+__device__ __forceinline__ void grid_setup(const RtBuildDev& b);
 
 // Scene bounds (Serial/grid.h:82-86): min/max over all vertices, taken over the triangles' boxes. Exact and
 // order-independent.
+// FUSED (small meshes, where every launch counts): the block that finishes last also sets the grid up. For large meshes
+// the fences this needs cost more than the launch of k_grid_setup saves.
+template <bool FUSED>
 __global__ void __launch_bounds__(256) k_bounds(RtBuildDev b) {
     __shared__ float red[4][6];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -136,18 +145,31 @@ __global__ void __launch_bounds__(256) k_bounds(RtBuildDev b) {
         if (a < 3) atomicMin(&b.bounds_enc[a], enc_f32(v));
         else atomicMax(&b.bounds_enc[a], enc_f32(v));
     }
+    if (FUSED) {
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (atomicAdd(&b.bounds_enc[6], 1u) == gridDim.x - 1u) {
+                __threadfence();
+                grid_setup(b);
+            }
+        }
+    }
 }
 
 // Resolution and voxel widths, Serial/grid.h:88-107. One thread: a few dozen scalar float operations.
-__global__ void k_grid_setup(RtBuildDev b) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void grid_setup(const RtBuildDev& b) {
     RtGrid* g = b.grid;
     float delta[3];
     for (int a = 0; a < 3; ++a) {
-        g->lo[a] = dec_f32(b.bounds_enc[a]);
-        g->hi[a] = dec_f32(b.bounds_enc[3 + a]);
+        g->lo[a] = dec_f32(__hip_atomic_load(&b.bounds_enc[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        g->hi[a] = dec_f32(__hip_atomic_load(&b.bounds_enc[3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         delta[a] = g->hi[a] - g->lo[a];
     }
+    // ready for the next build
+    for (int a = 0; a < 3; ++a) { b.bounds_enc[a] = 0xff800000u; b.bounds_enc[3 + a] = 0x007fffffu; }
+    b.bounds_enc[6] = 0;
+    g->overflow = 0;
     // boundingBox::maxAxis, Serial/geometry.h:276-285: strict '>' so ties go to the later axis
     int ax = (delta[0] > delta[1]) ? 0 : 1;
     if (ax) ax = (delta[1] > delta[2]) ? 1 : 2; else ax = (delta[0] > delta[2]) ? 0 : 2;
@@ -162,6 +184,11 @@ __global__ void k_grid_setup(RtBuildDev b) {
         cells *= nv;
     }
     g->n_cells = cells;
+}
+
+// Scene without triangles: no k_bounds, the set-up alone.
+__global__ void k_grid_setup(RtBuildDev b) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) grid_setup(b);
 }
 
 // Voxel range of one triangle's bounding box, Serial/grid.h:121-131.
@@ -315,7 +342,11 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const RtGrid g = *b.grid;
-    if (g.n_refs > b.ref_cap) { if (i == 0) b.grid->overflow = 1; return; }
+    if (g.n_refs > b.ref_cap) {              // cannot scatter: flag it and leave cell_count clear for the next build
+        if (i == 0) b.grid->overflow = 1;
+        for (uint32_t c = i; c < RT_MAX_CELLS; c += gridDim.x * blockDim.x) b.cell_count[c] = 0;
+        return;
+    }
     const bool valid = i < b.n_tris;
     int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
     if (valid) tri_voxel_range(b, g, i, vmin, vmax);
@@ -348,7 +379,11 @@ __global__ void __launch_bounds__(256) k_scatter_wide(RtBuildDev b) {
     const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const RtGrid g = *b.grid;
-    if (g.n_refs > b.ref_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) b.grid->overflow = 1; return; }
+    if (g.n_refs > b.ref_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) b.grid->overflow = 1;
+        for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < RT_MAX_CELLS; c += gridDim.x * blockDim.x) b.cell_count[c] = 0;
+        return;
+    }
     if (i >= b.n_tris) return;
     int vmin[3], vmax[3];
     tri_voxel_range(b, g, i, vmin, vmax);
@@ -610,13 +645,15 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
     }
 }
 
-hipError_t rt_launch_build_phase1(RtBuildDev b, hipStream_t st) {
-    k_build_init<<<256, 256, 0, st>>>(b);
-    if (b.n_tris) {
-        uint32_t nb = (b.n_tris + 255) / 256;
-        k_bounds<<<nb < 256 ? nb : 256, 256, 0, st>>>(b);
+hipError_t rt_launch_build_phase1(RtBuildDev b, bool first, hipStream_t st) {
+    if (first) k_build_init<<<256, 256, 0, st>>>(b);
+    if (b.n_tris && b.n_tris <= RT_WIDE_MAX_TRIS) {
+        const uint32_t nb = (b.n_tris + 255) / 256;
+        k_bounds<true><<<nb < 256 ? nb : 256, 256, 0, st>>>(b);    // its last block sets the grid up
+    } else {
+        if (b.n_tris) k_bounds<false><<<256, 256, 0, st>>>(b);
+        k_grid_setup<<<1, 64, 0, st>>>(b);
     }
-    k_grid_setup<<<1, 64, 0, st>>>(b);
     if (b.n_tris && b.n_tris <= RT_WIDE_MAX_TRIS) k_count_wide<<<(b.n_tris + 3) / 4, 256, 0, st>>>(b);
     else if (b.n_tris) k_count<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
     k_scan_sums<<<RT_MAX_SCAN_BLOCKS, 256, 0, st>>>(b);

@@ -213,6 +213,25 @@ def test_both_trace_kernels_give_the_golden_image(rt, plane10, monkeypatch, own,
         s.close()
 
 
+def test_scene_grows_between_frames(rt, plane10):
+    """The build kernels leave their counters reset for the next build of the scene; a triangle list that grows after
+    frames have been rendered starts from scratch and gives the frames of a scene that was loaded in one go."""
+    g_ids, g_rgb = golden("main_512x512")
+    s = rt.Scene(); s.load_mesh(SPOT)
+    p = rt.default_params(512, 512)
+    for _ in range(2):
+        s.render(p)
+    s.load_mesh(BLUB, True, (255, 0, 0), (1.5, 0, 0))
+    for _ in range(3):
+        rgb, _, ids = s.render(p)
+        check_image(rgb, ids, g_rgb, g_ids)
+    start, tris = s.grid_csr()
+    s.build_grid(); s.build_grid()
+    start2, tris2 = s.grid_csr()
+    assert np.array_equal(start, start2) and np.array_equal(tris, tris2)
+    s.close()
+
+
 def _rows_against_oracle(rt, O, s, o, W, H, row_blocks, walk_mode):
     """Whole frame on the GPU, sampled row blocks on the CPU oracle (full walk, as the reference runs)."""
     rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=walk_mode))
