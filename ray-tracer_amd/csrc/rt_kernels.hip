@@ -992,17 +992,24 @@ __device__ __forceinline__ void estimate_walk(const RtSceneDev& s, const GridU& 
     tris = c; voxels = met;
 }
 
+// SPLIT (small meshes: few tiles, and the frame waits for this kernel): eight lanes per tile, four in the first two
+// wavefronts of the block walk the primary sample rays and four in the other two the stand-in shadow rays; a shadow lane
+// first repeats its primary ray up to the first occupied voxel. A wavefront then has one walk behind it instead of two.
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, const uint32_t* work, const uint32_t* tile_list,
                                                   uint32_t* cost, unsigned long long* cost_sum, uint32_t* feat_by_tile, uint32_t n_tiles, float4 wgt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
     const uint32_t n = work[0];
-    if (blockIdx.x * (blockDim.x >> 2) >= n) return;
+    constexpr int LANES_LOG = SPLIT ? 3 : 2;
+    if (blockIdx.x * (blockDim.x >> LANES_LOG) >= n) return;
     bitmap_to_lds(bitmap, s.occupancy, (s.grid->n_cells + 31) >> 5);
     uint32_t* cells = bitmap + ((s.grid->n_cells + 31) >> 5);
-    // four lanes per tile, one sample pixel each: (1,1), (6,1), (1,6), (6,6)
-    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    // four lanes per tile and ray kind, one sample pixel each: (1,1), (6,1), (1,6), (6,6)
+    const uint32_t i = SPLIT ? blockIdx.x * 32u + ((threadIdx.x & 127u) >> 2) : (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const int smp = threadIdx.x & 3;
+    const bool shadow_lane = SPLIT && (threadIdx.x & 128);
+    __shared__ uint32_t shadow_sums[2][32];
     uint32_t c = 0;
     uint32_t tp = 0, vp = 0, ts = 0, vs = 0;
     int tile = 0;
@@ -1014,9 +1021,23 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
         const GridU g = load_grid(s.grid);
         float dx, dy, dz;
         primary_ray(cam, f, x, y, dx, dy, dz);
-        float t_first, unused;
-        estimate_walk(s, g, bitmap, cells, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, tp, vp, t_first);
-        if (t_first >= 0.f) {
+        float t_first = -1.f, unused;
+        if (!shadow_lane) {
+            estimate_walk(s, g, bitmap, cells, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, tp, vp, t_first);
+        } else {
+            float rayT;
+            if (grid_entry(g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, rayT)) {
+                Dda w;
+                dda_setup(w, g, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, rayT);
+                bool alive = true;
+                float t_in = rayT;
+                while (alive) {
+                    if ((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u) { t_first = t_in; break; }
+                    alive = dda_advance(w, false, 0.f, 0.f, &t_in);
+                }
+            }
+        }
+        if (t_first >= 0.f && (shadow_lane || !SPLIT)) {
             const float px = cam.pos[0] + dx * t_first, py = cam.pos[1] + dy * t_first, pz = cam.pos[2] + dz * t_first;
             float sx = px - sh.light[0], sy = py - sh.light[1], sz = pz - sh.light[2];
             normalize3(sx, sy, sz);
@@ -1026,7 +1047,13 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
     // the tile's numbers: sums over its four samples (neighbouring lanes)
     tp += __shfl_xor(tp, 1); vp += __shfl_xor(vp, 1); ts += __shfl_xor(ts, 1); vs += __shfl_xor(vs, 1);
     tp += __shfl_xor(tp, 2); vp += __shfl_xor(vp, 2); ts += __shfl_xor(ts, 2); vs += __shfl_xor(vs, 2);
-    if (i < n && smp == 0) {
+    if (SPLIT) {
+        const int slot = (threadIdx.x & 127) >> 2;
+        if (shadow_lane && smp == 0) { shadow_sums[0][slot] = ts; shadow_sums[1][slot] = vs; }
+        __syncthreads();
+        if (!shadow_lane) { ts = shadow_sums[0][slot]; vs = shadow_sums[1][slot]; }
+    }
+    if (i < n && smp == 0 && !shadow_lane) {
         const float e = wgt.x * (float)tp + wgt.y * (float)vp + wgt.z * (float)ts + wgt.w * (float)vs;
         c = e < 4.0e9f ? (uint32_t)e : 4000000000u;
         cost[i] = c;
@@ -1863,8 +1890,12 @@ hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame
     if (n_cls > 16384) k_classify<16><<<(n_cls + 63) / 64, 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
     else k_classify<4><<<(n_cls + 15) / 16, 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
     const int nb = (n_cls + 255) / 256;
-    k_estimate<<<(n_cls + 63) / 64, 256, (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles,
-                                                                                        make_float4(wk.est_w[0], wk.est_w[1], wk.est_w[2], wk.est_w[3]));
+    const float4 est_w = make_float4(wk.est_w[0], wk.est_w[1], wk.est_w[2], wk.est_w[3]);
+    const size_t est_lds = (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4;
+    if (s.n_tris <= RT_WIDE_MAX_TRIS)
+        k_estimate<true><<<(n_cls + 31) / 32, 256, est_lds, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles, est_w);
+    else
+        k_estimate<false><<<(n_cls + 63) / 64, 256, est_lds, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles, est_w);
     k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.lists, wk.list_cap, wk.thr0, wk.thr1, trace_blocks(f, wk) * RT_WAVES_PER_BLOCK,
                                 (unsigned long long)f.unit_shifts, f.adapt_units, s.grid);
     return hipGetLastError();
