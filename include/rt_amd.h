@@ -61,7 +61,7 @@ typedef struct rt_params {
 #define RT_BAND_ROWS 8
 #define RT_STATS_RING 128
 
-/* Device-side timings (hipEvents on the render stream) and counters of the last frame. */
+/* Device-side timings (hipEvents on the render stream) and the ray counts of the last frame. */
 typedef struct rt_frame_stats {
     float ms_build;                   /* grid build: bounds, count, scan, scatter, sort/record emit */
     float ms_render;                  /* render kernel incl. framebuffer writes */
@@ -70,19 +70,6 @@ typedef struct rt_frame_stats {
     uint32_t n_cells, n_refs;
     uint64_t n_triangles;
     uint64_t primary_rays, hits, shadowed;
-    /* filled only while rt_scene_set_counting(s, 1) is in effect (the counting kernel is slower): */
-    uint64_t primary_entering, steps_primary, tests_primary;   /* rays that enter the grid, voxels visited, triangle tests */
-    uint64_t shadow_entering, steps_shadow, tests_shadow;
-    /* scheduling diagnostics of the counting kernel: rounds of the wavefront walk, voxel streams and lanes
-     * served over all rounds, shader-clock cycles per traced tile (max, sum), traced tiles, most rounds in one tile */
-    uint64_t sched_rounds, sched_streams, sched_lanes /* cycles in the step phase */, tile_cycles_max, tile_cycles_sum, tiles_traced, tile_rounds_max,
-        cycles_test /* cycles in the test phase */,
-        tests_executed /* triangle tests actually run: runs whose box the ray's line misses are skipped */,
-        runs_streamed /* 64-record runs read by wavefronts */,
-        run_ray_trips /* (run, ray) iterations of the test loop */,
-        cycles_cull /* cycles in the run culling */,
-        wave_cycles_max /* busiest wavefront: cycles inside work units */,
-        span_cycles /* first wavefront start to last wavefront end */;
 } rt_frame_stats;
 
 const char* rt_last_error(void);
@@ -127,25 +114,13 @@ int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_grid, void* d_
 int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id);
 /* render() including its file output: writes "P6\nW H\n255\n" + body to `path` ("./test.ppm" in the reference). */
 int rt_render_ppm(rt_scene* s, const rt_params* p, const char* path);
-/* Stats of the last rt_render_device()/rt_render() on this scene; synchronises on its events. */
+/* Stats of the last rt_render_device()/rt_render() on this scene; synchronises on its events. Work counters and
+ * scheduling diagnostics of the counting build of the kernels are declared in rt_amd_diag.h. */
 int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out);
 /* Timings of the frame rendered `frames_back` frames before the last one (0 = last; a ring of RT_STATS_RING
- * frames is kept, so a benchmark can time a whole run without synchronising inside it). Counters are
+ * frames is kept, so a benchmark can time a whole run without synchronising inside it). Ray counts are
  * those of the last frame. */
 int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stats* out);
-/* Diagnostics of the last counting frame, as 32-bit words; with t = tiles of the frame (8x8 pixels each):
- * [0, 16t) shader cycles of every work unit in queue order (0 = unused slot), [16t, 20t) the four numbers the cost
- * estimate of every tile is made of, [20t, 21t) shader cycles per tile, [21t, 37t) per work unit: tile | unit shift << 24
- * | queue list << 28, [37t, 53t) per work unit: (run, ray) test iterations | record runs streamed << 18 (both saturate),
- * [53t, 69t) per work unit: cycles / 256 spent stepping | cycles / 256 spent culling runs << 16, [69t, 85t) per work
- * unit: cycles / 256 spent testing | rounds << 24, [85t, 101t) per work unit: its start on the 100 MHz
- * real-time clock (low 20 bits) | its duration on that clock / 64 << 20.
- * 112t words in all. Returns the number of words copied (at most n).
- * No counterpart in the reference. */
-int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n);
-/* Work accounting: when enabled, frames also count voxel steps and triangle tests per ray class. */
-int rt_scene_set_counting(rt_scene* s, int32_t enable);
-
 /* Self-test of the arithmetic of the triangle test (no counterpart in the reference): the kernels divide three
  * numerators by one denominator with a shared reciprocal refinement where the operands' exponents are within 2^+-300;
  * this runs that form and the plain division on the n pairs (num[i], den[i]) on the GPU and returns the number of

@@ -1,0 +1,46 @@
+/* rt_amd_diag.h - diagnostics of the MI355X render path: work counters and scheduling measurements of the
+ * counting build of the kernels. None of this has a counterpart in the reference; tools/ and bench.py use it to
+ * report the algorithmic work of a frame (voxel steps, triangle tests) and to study the schedule of the trace kernel.
+ */
+#ifndef RT_AMD_DIAG_H
+#define RT_AMD_DIAG_H
+#include "rt_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Counters of the last frame rendered while rt_scene_set_counting(s, 1) was in effect (the counting kernel is slower). */
+typedef struct rt_frame_counts {
+    uint64_t primary_entering, steps_primary, tests_primary;   /* rays that enter the grid, voxels visited, triangle tests */
+    uint64_t shadow_entering, steps_shadow, tests_shadow;
+    /* scheduling diagnostics of the counting kernel: rounds of the wavefront walk, voxel streams and lanes
+     * served over all rounds, shader-clock cycles per traced tile (max, sum), traced tiles, most rounds in one tile */
+    uint64_t sched_rounds, sched_streams, sched_lanes /* cycles in the step phase */, tile_cycles_max, tile_cycles_sum, tiles_traced, tile_rounds_max,
+        cycles_test /* cycles in the test phase */,
+        tests_executed /* triangle tests actually run: runs whose box the ray's line misses are skipped */,
+        runs_streamed /* 64-record runs read by wavefronts */,
+        run_ray_trips /* (run, ray) iterations of the test loop */,
+        cycles_cull /* cycles in the run culling */,
+        wave_cycles_max /* busiest wavefront: cycles inside work units */,
+        span_cycles /* first wavefront start to last wavefront end */;
+} rt_frame_counts;
+
+/* Work accounting: when enabled, frames also count voxel steps and triangle tests per ray class. */
+int rt_scene_set_counting(rt_scene* s, int32_t enable);
+/* Counters of the last frame (zeros unless it was a counting frame); synchronises the device. */
+int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out);
+/* Diagnostics of the last counting frame, as 32-bit words; with t = tiles of the frame (8x8 pixels each):
+ * [0, 16t) shader cycles of every work unit in queue order (0 = unused slot), [16t, 20t) the four numbers the cost
+ * estimate of every tile is made of, [20t, 21t) shader cycles per tile, [21t, 37t) per work unit: tile | unit shift << 24
+ * | queue list << 28, [37t, 53t) per work unit: (run, ray) test iterations | record runs streamed << 18 (both saturate),
+ * [53t, 69t) per work unit: cycles / 256 spent stepping | cycles / 256 spent culling runs << 16, [69t, 85t) per work
+ * unit: cycles / 256 spent testing | rounds << 24, [85t, 101t) per work unit: its start on the 100 MHz
+ * real-time clock (low 20 bits) | its duration on that clock / 64 << 20.
+ * 112t words in all. Returns the number of words copied (at most n).
+ * No counterpart in the reference. */
+int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

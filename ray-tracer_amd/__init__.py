@@ -36,11 +36,26 @@ class Params(C.Structure):
     ]
 
 
+def _as_dict(st):
+    d = {}
+    for n, _ in st._fields_:
+        v = getattr(st, n)
+        d[n] = list(v) if hasattr(v, "__len__") else v
+    return d
+
+
 class FrameStats(C.Structure):
+    """rt_frame_stats of include/rt_amd.h."""
     _fields_ = [
         ("ms_build", C.c_float), ("ms_render", C.c_float), ("ms_total", C.c_float),
         ("grid_n", C.c_int32 * 3), ("n_cells", C.c_uint32), ("n_refs", C.c_uint32),
         ("n_triangles", C.c_uint64), ("primary_rays", C.c_uint64), ("hits", C.c_uint64), ("shadowed", C.c_uint64),
+    ]
+
+
+class FrameCounts(C.Structure):
+    """rt_frame_counts of include/rt_amd_diag.h."""
+    _fields_ = [
         ("primary_entering", C.c_uint64), ("steps_primary", C.c_uint64), ("tests_primary", C.c_uint64),
         ("shadow_entering", C.c_uint64), ("steps_shadow", C.c_uint64), ("tests_shadow", C.c_uint64),
         ("sched_rounds", C.c_uint64), ("sched_streams", C.c_uint64), ("sched_lanes", C.c_uint64),
@@ -50,20 +65,13 @@ class FrameStats(C.Structure):
         ("wave_cycles_max", C.c_uint64), ("span_cycles", C.c_uint64),
     ]
 
-    def as_dict(self):
-        d = {}
-        for n, _ in self._fields_:
-            v = getattr(self, n)
-            d[n] = list(v) if hasattr(v, "__len__") else v
-        return d
 
-
-# every symbol include/rt_amd.h declares
+# every symbol include/rt_amd.h and include/rt_amd_diag.h declare
 EXPORTS = [
     "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
-    "rt_render_device", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_unit_costs",
+    "rt_render_device", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_unit_costs",
     "rt_deinterleave_device", "rt_selftest_division",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
@@ -111,8 +119,8 @@ def lib():
     L.rt_scene_last_stats.argtypes = [vp, vp]
     L.rt_scene_stats_at.argtypes = [vp, i32, vp]
     L.rt_scene_set_counting.argtypes = [vp, i32]
-    if hasattr(L, "rt_scene_unit_costs"):
-        L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
+    L.rt_scene_last_counts.argtypes = [vp, vp]
+    L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
     L.rt_deinterleave_device.argtypes = [vp, vp, vp, i32, vp]
     L.rt_selftest_division.argtypes = [vp, vp, i64]
     L.rt_selftest_division.restype = i64
@@ -221,14 +229,18 @@ class Scene:
         _check(lib().rt_render_ppm(self.h, C.byref(params), os.fsencode(path)))
 
     def last_stats(self):
-        st = FrameStats()
+        """Timings and ray counts of the last frame plus the work counters of the counting build (zeros otherwise)."""
+        st, cn = FrameStats(), FrameCounts()
         _check(lib().rt_scene_last_stats(self.h, C.byref(st)))
-        return st.as_dict()
+        _check(lib().rt_scene_last_counts(self.h, C.byref(cn)))
+        d = _as_dict(st)
+        d.update(_as_dict(cn))
+        return d
 
     def stats_at(self, frames_back):
         st = FrameStats()
         _check(lib().rt_scene_stats_at(self.h, frames_back, C.byref(st)))
-        return st.as_dict()
+        return _as_dict(st)
 
     def unit_costs(self, n):
         out = np.zeros(n, np.uint32)

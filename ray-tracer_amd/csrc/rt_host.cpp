@@ -2,6 +2,7 @@
 // camera set-up, device memory management, frame orchestration and the C ABI of include/rt_amd.h.
 // No CPU rendering lives here: every compute entry point launches the HIP kernels of rt_kernels.hip.
 #include "../../include/rt_amd.h"
+#include "../../include/rt_amd_diag.h"
 #include "rt_device.h"
 
 #include <math.h>
@@ -10,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <string>
 #include <vector>
 
@@ -31,6 +33,12 @@ static int set_err(int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                         \
         if (e_ != hipSuccess) return set_err(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// Entry points whose bodies allocate host memory (std::vector): no C++ exception may cross the C boundary.
+#define RT_GUARD(T, call)                                                                               \
+    try { return (call); }                                                                              \
+    catch (const std::bad_alloc&) { return (T)set_err(RT_ERR_NOMEM, "out of host memory"); }            \
+    catch (...) { return (T)set_err(RT_ERR_INVALID, "unexpected C++ exception"); }
 
 extern "C" const char* rt_last_error(void) { return g_err; }
 extern "C" const char* rt_version(void) { return "rt_amd 0.1 (gfx950)"; }
@@ -92,11 +100,28 @@ struct rt_scene {
     uint64_t sched_shifts = 0x2222000022223333ull;
     bool sched_adapt = true;               // off when RT_SHIFTS gives the unit sizes explicitly
     float est_w[4] = {1.f, 500.f, 0.f, 700.f};    // cost estimate weights: primary triangles, primary voxels, shadow triangles, shadow voxels
-    hipStream_t last_stream = nullptr;
+    hipStream_t last_stream = nullptr;       // stream of the last frame or grid build (build state is shared between frames)
+    bool stream_used = false;
     hipStream_t side_stream = nullptr;       // work-list preparation beside the grid build
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr;
+    hipEvent_t ev_done = nullptr;            // end of the last frame or grid build on last_stream
     rt_params last_params;
+    // experiment overrides, read once when the scene is created: RT_OWN_PATH (-1 = the library decides), RT_CULL_MIN
+    // (1..65535), RT_CULL_LANE_RUNS (0..64), RT_BLOCKS_PER_CU (0 = no cap)
+    int own_path_override = -1;
+    int cull_min = 64, cull_lane_runs = 12;
+    int blocks_per_cu_cap = 0;
+    size_t n_tris() const { return tri_mesh.size(); }
 };
+
+static int env_int(const char* name, int lo, int hi, int dflt) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (!end || *end != 0) return dflt;
+    return v < lo ? lo : (v > hi ? hi : (int)v);
+}
 
 extern "C" rt_scene* rt_scene_create(void) {
     rt_scene* s = new (std::nothrow) rt_scene();
@@ -112,6 +137,10 @@ extern "C" rt_scene* rt_scene_create(void) {
             for (int k = 0; k < 16 && ok; ++k) ok = ((v >> (4 * k)) & 15ull) <= 4;
             if (ok) { s->sched_shifts = v; s->sched_adapt = false; }
         }
+        s->own_path_override = env_int("RT_OWN_PATH", 0, 1, -1);
+        s->cull_min = env_int("RT_CULL_MIN", 1, 65535, 64);
+        s->cull_lane_runs = env_int("RT_CULL_LANE_RUNS", 0, 64, 12);
+        s->blocks_per_cu_cap = env_int("RT_BLOCKS_PER_CU", 1, 64, 0);
     }
     return s;
 }
@@ -127,6 +156,8 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
         if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
         if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+        if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+        if (s->ev_start) (void)hipEventDestroy(s->ev_start);
         if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
     }
     delete s;
@@ -134,7 +165,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
 
 static void scene_touch(rt_scene* s) { s->uploaded = false; s->grid_valid = false; s->refs_known = false; s->build_clean = false; }
 
-extern "C" int64_t rt_scene_add_triangles(rt_scene* s, const float* v9, int64_t n, const float color[3]) {
+static int64_t add_triangles_impl(rt_scene* s, const float* v9, int64_t n, const float color[3]) {
     if (!s || n < 0 || (n > 0 && !v9) || !color) return set_err(RT_ERR_INVALID, "rt_scene_add_triangles: bad argument");
     if ((uint64_t)s->tri_mesh.size() + (uint64_t)n >= 0x7fffffffull) return set_err(RT_ERR_INVALID, "too many triangles");
     uint32_t mesh = (uint32_t)(s->mesh_color.size() / 3);
@@ -143,6 +174,10 @@ extern "C" int64_t rt_scene_add_triangles(rt_scene* s, const float* v9, int64_t 
     s->tri_mesh.insert(s->tri_mesh.end(), (size_t)n, mesh);
     scene_touch(s);
     return n;
+}
+
+extern "C" int64_t rt_scene_add_triangles(rt_scene* s, const float* v9, int64_t n, const float color[3]) {
+    RT_GUARD(int64_t, add_triangles_impl(s, v9, n, color))
 }
 
 extern "C" int64_t rt_scene_num_triangles(const rt_scene* s) { return s ? (int64_t)s->tri_mesh.size() : 0; }
@@ -161,17 +196,21 @@ extern "C" int rt_scene_get_triangles(const rt_scene* s, float* v9) {
 
 static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
 
-extern "C" int64_t rt_scene_add_obj(rt_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]) {
+static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]) {
     (void)format_has_vt;   // the texture index is parsed by the reference but never used by the path
     if (!s || !path || !color || !offset) return set_err(RT_ERR_INVALID, "rt_scene_add_obj: bad argument");
     FILE* f = fopen(path, "rb");
     if (!f) return 0;   // like the reference: a missing file is an empty mesh
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    std::vector<char> buf((size_t)sz + 1);
-    size_t got = fread(buf.data(), 1, (size_t)sz, f);
+    // a directory, a pipe or any other path that cannot be sized and read whole is an I/O error, not an empty mesh
+    long sz = -1;
+    if (fseek(f, 0, SEEK_END) == 0) sz = ftell(f);
+    if (sz < 0 || sz > (long)0x7fffffff00l || fseek(f, 0, SEEK_SET) != 0) { fclose(f); return set_err(RT_ERR_IO, "%s: cannot determine the file size", path); }
+    std::vector<char> buf;
+    try { buf.resize((size_t)sz + 1); } catch (...) { fclose(f); throw; }
+    const size_t got = fread(buf.data(), 1, (size_t)sz, f);
+    const bool read_err = ferror(f) != 0;
     fclose(f);
+    if (read_err || got > (size_t)sz) return set_err(RT_ERR_IO, "%s: read error", path);
     buf[got] = 0;
 
     std::vector<float> verts;
@@ -235,6 +274,16 @@ extern "C" int64_t rt_scene_add_obj(rt_scene* s, const char* path, int format_ha
     s->mesh_color.insert(s->mesh_color.end(), color, color + 3);
     scene_touch(s);
     return (int64_t)(s->tri_mesh.size() - tri_before);
+}
+
+extern "C" int64_t rt_scene_add_obj(rt_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]) {
+    const size_t tris_before = s ? s->tri_mesh.size() : 0, meshes_before = s ? s->mesh_color.size() : 0;
+    try { return add_obj_impl(s, path, format_has_vt, color, offset); }
+    catch (...) {
+        // out of memory half way through the file: the triangle list is left as it was
+        if (s) { s->tri.resize(tris_before * 9); s->tri_mesh.resize(tris_before); s->mesh_color.resize(meshes_before); }
+        return set_err(RT_ERR_NOMEM, "out of host memory while reading %s", path ? path : "(null)");
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -308,23 +357,83 @@ static int scene_bind_device(rt_scene* s) {
         for (auto& slot : s->ev) for (auto& ev : slot) HIP_TRY(hipEventCreate(&ev));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_start, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
     }
     return RT_OK;
 }
 
-static RtBuildDev build_args(rt_scene* s) {
+// Working memory of a frame: everything the grid build and the render kernels write besides the caller's outputs.
+// A scene owns one set (allocated on demand, reused by later frames).
+struct FrameMem {
+    RtGrid* grid = nullptr;
+    uint32_t *bounds_enc = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr, *occupancy = nullptr;
+    uint32_t *ref_tri = nullptr, *ref_cell = nullptr;
+    uint2* row_minmax = nullptr;
+    float4 *recs = nullptr, *blk_bounds = nullptr;
+    size_t ref_cap = 0;                      // references the five arrays above can hold
+    unsigned long long* counters = nullptr;  // RT_COUNTER_WORDS
+    uint32_t *tile_list = nullptr, *tile_cost = nullptr, *queue_lists = nullptr;
+    size_t tile_cap = 0;                     // tiles the three lists above can hold (queue_lists: RT_QUEUE_LISTS times as many)
+    uint32_t* unit_cost = nullptr;           // counting frames only: 112 words per tile
+};
+#define RT_COUNTER_WORDS 88                  // 24 frame counters, 32 work-list words (64 x u32), 32 partial sums of the cost estimate
+
+static FrameMem scene_mem(rt_scene* s) {
+    FrameMem m;
+    m.grid = s->d_grid.p; m.bounds_enc = s->bounds_enc.p; m.cell_count = s->cell_count.p; m.cell_start = s->cell_start.p;
+    m.block_sums = s->block_sums.p; m.occupancy = s->occupancy.p;
+    m.ref_tri = s->ref_tri.p; m.ref_cell = s->ref_cell.p; m.row_minmax = s->row_minmax.p; m.recs = s->recs.p; m.blk_bounds = s->blk_bounds.p;
+    m.ref_cap = s->ref_tri.cap;
+    m.counters = s->counters.p;
+    m.tile_list = s->tile_list.p; m.tile_cost = s->tile_cost.p; m.queue_lists = s->queue_lists.p; m.tile_cap = s->tile_list.cap;
+    m.unit_cost = s->unit_cost.p;
+    return m;
+}
+
+static RtBuildDev build_args(rt_scene* s, const FrameMem& m) {
     RtBuildDev b;
     b.v0 = s->v0.p; b.v1 = s->v1.p; b.v2 = s->v2.p; b.tri_rec = s->tri_rec.p; b.tri_box = s->tri_box.p;
-    b.n_tris = (uint32_t)s->tri_mesh.size();
-    b.cube_root = 3.f * powf((float)s->tri_mesh.size(), 1.f / 3.f);   // Serial/grid.h:94, host libm
-    b.grid = s->d_grid.p;
-    b.bounds_enc = s->bounds_enc.p;
-    b.cell_count = s->cell_count.p; b.cell_start = s->cell_start.p; b.block_sums = s->block_sums.p; b.occupancy = s->occupancy.p;
-    b.ref_tri = s->ref_tri.p; b.ref_cell = s->ref_cell.p; b.row_minmax = s->row_minmax.p; b.recs = s->recs.p; b.blk_bounds = s->blk_bounds.p;
-    b.ref_cap = (uint32_t)s->ref_tri.cap;
-    b.counters = s->counters.p;
+    b.n_tris = (uint32_t)s->n_tris();
+    b.cube_root = 3.f * powf((float)s->n_tris(), 1.f / 3.f);   // Serial/grid.h:94, host libm
+    b.grid = m.grid;
+    b.bounds_enc = m.bounds_enc;
+    b.cell_count = m.cell_count; b.cell_start = m.cell_start; b.block_sums = m.block_sums; b.occupancy = m.occupancy;
+    b.ref_tri = m.ref_tri; b.ref_cell = m.ref_cell; b.row_minmax = m.row_minmax; b.recs = m.recs; b.blk_bounds = m.blk_bounds;
+    b.ref_cap = (uint32_t)m.ref_cap;
+    b.counters = m.counters;
     return b;
+}
+
+// The scene's build state (counters the build kernels leave reset, the work list, the fork/join events) is shared between
+// frames, so consecutive frames and grid builds of one scene have to be ordered. On one stream they are; when the caller
+// switches streams the new stream first waits for the end of the work enqueued on the old one.
+static int scene_enter_stream(rt_scene* s, hipStream_t st) {
+    if (s->stream_used && st != s->last_stream) HIP_TRY(hipStreamWaitEvent(st, s->ev_done, 0));
+    return RT_OK;
+}
+static int scene_leave_stream(rt_scene* s, hipStream_t st) {
+    HIP_TRY(hipEventRecord(s->ev_done, st));
+    s->last_stream = st;
+    s->stream_used = true;
+    return RT_OK;
+}
+
+// First half of a grid build on the scene's own memory, synchronously: how many (voxel, triangle) references the current
+// triangle list has and what its grid looks like. Known before any frame, so that frames never wait for the device.
+static int scene_measure_grid(rt_scene* s) {
+    if (s->refs_known) return RT_OK;
+    HIP_TRY(rt_launch_build_phase1(build_args(s, scene_mem(s)), true, nullptr));
+    RtGrid g;
+    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    s->known_refs = g.n_refs;
+    s->known_cells = (uint32_t)g.n_cells;
+    s->h_grid = g;
+    s->refs_known = true;
+    s->build_clean = false;      // the count was not consumed by a scatter
+    s->grid_valid = false;
+    return RT_OK;
 }
 
 extern "C" int rt_scene_upload(rt_scene* s) {
@@ -332,14 +441,15 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     int rc = scene_bind_device(s);
     if (rc) return rc;
     if (s->uploaded) return RT_OK;
-    const size_t T = s->tri_mesh.size();
+    const size_t T = s->n_tris();
     const size_t Tn = T ? T : 1;
     if ((rc = s->v0.ensure(Tn)) || (rc = s->v1.ensure(Tn)) || (rc = s->v2.ensure(Tn)) || (rc = s->tri_rec.ensure(3 * Tn)) || (rc = s->tri_box.ensure(3 * Tn))) return rc;
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
-        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(88)))
+        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(RT_COUNTER_WORDS)))
         return rc;
+    HIP_TRY(hipDeviceSynchronize());         // frames of the previous triangle list may still be reading these buffers
     HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
     HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(s->occupancy.p, 0, (RT_MAX_CELLS / 32 + 2) * sizeof(uint32_t)));
@@ -350,7 +460,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
         if ((rc = stage.ensure(9 * T)) || (rc = stage_mesh.ensure(T))) { stage.release(); stage_mesh.release(); return rc; }
         hipError_t e = hipMemcpy(stage.p, s->tri.data(), 9 * T * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(stage_mesh.p, s->tri_mesh.data(), T * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = rt_launch_upload_convert(stage.p, stage_mesh.p, build_args(s), nullptr);
+        if (e == hipSuccess) e = rt_launch_upload_convert(stage.p, stage_mesh.p, build_args(s, scene_mem(s)), nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         stage.release(); stage_mesh.release();
         if (e != hipSuccess) return set_err(RT_ERR_HIP, "scene upload: %s", hipGetErrorString(e));
@@ -360,32 +470,37 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     s->uploaded = true;
     s->grid_valid = false;
     s->build_clean = false;
+    s->refs_known = false;
+    return scene_measure_grid(s);
+}
+
+// Grid build on the working memory `m`. `first`: the build counters in `m` have not been left reset by a completed
+// build (k_build_init runs). `after_phase1`, when given, is recorded once cell_start and the occupancy bitmap are final
+// (the records are not yet).
+static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStream_t st, hipEvent_t after_phase1 = nullptr) {
+    if ((size_t)s->known_refs > m.ref_cap) return set_err(RT_ERR_INVALID, "grid build: %u references exceed the capacity %zu", s->known_refs, m.ref_cap);
+    HIP_TRY(rt_launch_build_phase1(build_args(s, m), first, st));
+    if (after_phase1) HIP_TRY(hipEventRecord(after_phase1, st));
+    HIP_TRY(rt_launch_build_phase2(build_args(s, m), st));
     return RT_OK;
 }
 
-// `after_phase1`, when given, is recorded once cell_start and the occupancy bitmap are final (the records are not yet).
-static int build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_phase1 = nullptr) {
+// The scene's own reference arrays, sized from the measured reference count.
+static int scene_ensure_refs(rt_scene* s) {
     int rc;
+    const size_t need = s->known_refs ? s->known_refs : 1;
+    if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)) ||
+        (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(3 * (need / 64 + 2))))
+        return rc;
+    return RT_OK;
+}
+
+static int scene_build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_phase1 = nullptr) {
+    int rc = scene_ensure_refs(s);
+    if (rc) return rc;
     const bool first = !s->build_clean;
     s->build_clean = false;
-    if (!s->refs_known) {
-        // First build of this triangle list: run count + scan, read the reference total back once and size
-        // the reference arrays from it. Later builds of the same list are fully asynchronous.
-        HIP_TRY(rt_launch_build_phase1(build_args(s), first, st));
-        RtGrid g;
-        HIP_TRY(hipMemcpyAsync(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        s->known_refs = g.n_refs;
-        s->known_cells = (uint32_t)g.n_cells;
-        s->h_grid = g;
-        s->refs_known = true;
-        size_t need = g.n_refs ? g.n_refs : 1;
-        if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)) || (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(3 * (need / 64 + 2)))) return rc;
-    } else {
-        HIP_TRY(rt_launch_build_phase1(build_args(s), first, st));
-    }
-    if (after_phase1) HIP_TRY(hipEventRecord(after_phase1, st));
-    HIP_TRY(rt_launch_build_phase2(build_args(s), st));
+    if ((rc = build_grid_async(s, scene_mem(s), first, st, after_phase1))) return rc;
     s->grid_valid = true;
     s->build_clean = true;
     return RT_OK;
@@ -395,7 +510,10 @@ extern "C" int rt_scene_build_grid(rt_scene* s, void* stream) {
     if (!s) return set_err(RT_ERR_INVALID, "rt_scene_build_grid: NULL scene");
     int rc = rt_scene_upload(s);
     if (rc) return rc;
-    return build_grid_async(s, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = scene_enter_stream(s, st))) return rc;
+    if ((rc = scene_build_grid_async(s, st))) return rc;
+    return scene_leave_stream(s, st);
 }
 
 extern "C" int rt_scene_get_grid(rt_scene* s, int32_t n[3], float lohi[6], float width[3], float inv_width[3], uint32_t* n_cells, uint32_t* n_refs) {
@@ -436,11 +554,18 @@ extern "C" int rt_scene_get_csr(rt_scene* s, uint32_t* cell_start, uint32_t* cel
 // ------------------------------------------------------------------------------------------------
 // render
 // ------------------------------------------------------------------------------------------------
+static bool finite3(const float v[3]) { return isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]); }
+
 static int check_params(const rt_params* p) {
     if (!p) return set_err(RT_ERR_INVALID, "NULL params");
     if (p->width <= 0 || p->height <= 0 || p->width > 65536 || p->height > 65536) return set_err(RT_ERR_INVALID, "bad frame size %dx%d", p->width, p->height);
     if (p->part_count < 1 || p->part_index < 0 || p->part_index >= p->part_count) return set_err(RT_ERR_INVALID, "bad partition %d/%d", p->part_index, p->part_count);
     if (p->walk_mode != RT_WALK_EARLY && p->walk_mode != RT_WALK_FULL) return set_err(RT_ERR_INVALID, "bad walk_mode %d", p->walk_mode);
+    // The reference has no such check (its parameters are literals); a non-finite camera, light or constant gives NaN rays
+    // and NaN hit distances, for which its own result is undefined (it reads a stale triangle pointer).
+    if (!finite3(p->cam_pos) || !finite3(p->cam_target) || !finite3(p->cam_up) || !finite3(p->light_pos) || !isfinite(p->fov) || !isfinite(p->kd) ||
+        !isfinite(p->ks) || !isfinite(p->ka) || !isfinite(p->spec_alpha) || !isfinite(p->light_intensity) || !isfinite(p->shadow_scale) || !isfinite(p->eps))
+        return set_err(RT_ERR_INVALID, "non-finite camera, light or shading parameter");
     return RT_OK;
 }
 
@@ -474,35 +599,42 @@ static void grid_tile_rect(const RtCamera& c, const RtGrid& g, int W, int H, int
     tx0 = (int)xmin / 8; tx1 = (int)xmax / 8; ty0 = (int)ymin / 8; ty1 = (int)ymax / 8;
 }
 
-extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_grid, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id, void* stream) {
-    if (!s) return set_err(RT_ERR_INVALID, "rt_render_device: NULL scene");
-    int rc = check_params(p);
-    if (rc) return rc;
-    if ((rc = rt_scene_upload(s))) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const int slot = (int)(s->frames % RT_STATS_RING);
-    HIP_TRY(hipEventRecord(s->ev[slot][0], st));
-    s->built[slot] = false;
+static size_t frame_tiles(const rt_params* p) {
+    const size_t t = (size_t)((p->width + 7) / 8) * (size_t)((rt_part_rows(p) + 7) / 8);
+    return t ? t : 1;
+}
+
+// One frame on the working memory `m`: clears the outputs, builds the grid when asked to, prepares the work list and
+// traces. `fork`: the scene's side stream and events may be used (work-list preparation beside the second half of the
+// build); without it everything is enqueued on `st` in order and nothing but kernels and memsets is issued.
+// `build`: 0 = the grid in `m` is current, 1 = rebuild, the build state in `m` was left clean, 2 = rebuild from scratch.
+static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int build, bool fork, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id,
+                        hipStream_t st, hipEvent_t ev_trace_start) {
+    int rc;
     // With a grid build in the frame, everything that only needs the grid's cell table (clearing the outputs, the tile list
     // and its cost classes) runs on a side stream beside the second half of the build and joins before the trace kernel.
     // The clearing needs nothing of the grid: the side stream does it beside the first half of the build (it starts where
     // the frame starts on `st`, that is after the frame before).
     // Small meshes only: their frame waits for the side stream, while the build of a large mesh is the longer branch and
     // its bounds kernel runs at half speed beside a 25 MB memset.
-    const bool rebuild = rebuild_grid || !s->grid_valid;
-    const bool clear_early = rebuild && s->tri_mesh.size() <= 65536;
+    const bool use_side = fork && build != 0;
+    const bool clear_early = use_side && s->n_tris() <= 65536;
     hipStream_t side = st;
-    if (rebuild) {
+    if (use_side) {
         side = s->side_stream;
-        if (clear_early) HIP_TRY(hipStreamWaitEvent(side, s->ev[slot][0], 0));
-        else {
-            if ((rc = build_grid_async(s, st, s->ev_fork))) return rc;
-            s->built[slot] = true;
+        if (clear_early) {
+            HIP_TRY(hipEventRecord(s->ev_start, st));
+            HIP_TRY(hipStreamWaitEvent(side, s->ev_start, 0));
+        } else {
+            if ((rc = build_grid_async(s, m, build == 2, st, s->ev_fork))) return rc;
             HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
         }
+    } else if (build != 0) {
+        if ((rc = build_grid_async(s, m, build == 2, st))) return rc;
     }
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 88 * sizeof(unsigned long long), side));
-    if (s->count_work) HIP_TRY(hipMemsetAsync(s->counters.p + 22, 0xff, sizeof(unsigned long long), side));   // slot of a minimum
+    const bool counting = s->count_work && m.unit_cost;
+    HIP_TRY(hipMemsetAsync(m.counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), side));
+    if (counting) HIP_TRY(hipMemsetAsync(m.counters + 22, 0xff, sizeof(unsigned long long), side));   // slot of a minimum
     {
         // background everywhere first: black, no hit
         const size_t out_px = (size_t)p->width * (size_t)rt_part_rows(p);
@@ -511,16 +643,15 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         if (d_hit_id) HIP_TRY(hipMemsetAsync(d_hit_id, 0xff, out_px * sizeof(int32_t), side));
     }
     if (clear_early) {
-        if ((rc = build_grid_async(s, st, s->ev_fork))) return rc;
-        s->built[slot] = true;
+        if ((rc = build_grid_async(s, m, build == 2, st, s->ev_fork))) return rc;
         HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
     }
 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
     sd.mesh_color = s->d_mesh_color.p;
-    sd.n_tris = (uint32_t)s->tri_mesh.size();
-    sd.grid = s->d_grid.p; sd.cell_start = s->cell_start.p; sd.occupancy = s->occupancy.p; sd.recs = s->recs.p; sd.blk_bounds = s->blk_bounds.p;
+    sd.n_tris = (uint32_t)s->n_tris();
+    sd.grid = m.grid; sd.cell_start = m.cell_start; sd.occupancy = m.occupancy; sd.recs = m.recs; sd.blk_bounds = m.blk_bounds;
     RtShade sh;
     for (int a = 0; a < 3; ++a) sh.light[a] = p->light_pos[a];
     sh.kd = p->kd; sh.ks = p->ks; sh.ka = p->ka; sh.spec_alpha = p->spec_alpha;
@@ -531,17 +662,17 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     f.out_rows = rt_part_rows(p);
     f.walk_full = (p->walk_mode == RT_WALK_FULL);
     f.early_slack = 0.f;
-    f.count_work = s->count_work ? 1 : 0;
+    f.count_work = counting ? 1 : 0;
     // A grid has at most RT_MAX_CELLS voxels: from two references per voxel on average it is crowded for certain, and the
-    // trace kernel without the path for voxels of a few records is used (RT_OWN_PATH=0/1 overrides, for experiments).
+    // trace kernel without the path for voxels of a few records is used.
     f.own_path = (s->known_refs >= 2u * (uint32_t)RT_MAX_CELLS) ? 0 : 1;
-    if (const char* e = getenv("RT_OWN_PATH")) f.own_path = atoi(e) ? 1 : 0;
+    if (s->own_path_override >= 0) f.own_path = s->own_path_override;
     f.unit_shifts = s->sched_shifts;
     f.adapt_units = s->sched_adapt ? 1 : 0;
-    { const char* e = getenv("RT_CULL_MIN"); const char* e2 = getenv("RT_CULL_LANE_RUNS"); f.cull_min = (e ? atoi(e) : 64) | ((e2 ? atoi(e2) : 12) << 16); }
+    f.cull_min = s->cull_min | (s->cull_lane_runs << 16);
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
-    o.counters = s->counters.p;
+    o.counters = m.counters;
     o.unit_cost = nullptr; o.tile_cycles = nullptr; o.unit_info = nullptr;
     const RtCamera cam = make_camera(p);
     RtRenderWork wk;
@@ -549,8 +680,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     {
         // tiles that can see the grid: full-frame tile rows ty0..ty1 -> local bands of this part
         int tx0, tx1, ty0, ty1;
-        if (s->refs_known) grid_tile_rect(cam, s->h_grid, p->width, p->height, tx0, tx1, ty0, ty1);
-        else { tx0 = 0; tx1 = (p->width + 7) / 8 - 1; ty0 = 0; ty1 = (p->height + 7) / 8 - 1; }
+        grid_tile_rect(cam, s->h_grid, p->width, p->height, tx0, tx1, ty0, ty1);
         const int pc = p->part_count, pi = p->part_index;
         int lb0 = (ty0 - pi + pc - 1) / pc;
         if (ty0 < pi) lb0 = 0;
@@ -558,48 +688,65 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
         wk.tx0 = tx0; wk.ntx = tx1 - tx0 + 1; wk.tb0 = lb0; wk.ntb = lb1 - lb0 + 1;
         if (wk.ntx < 0) wk.ntx = 0;
         if (wk.ntb < 0) wk.ntb = 0;
-        const size_t tiles = (size_t)((p->width + 7) / 8) * (size_t)((f.out_rows + 7) / 8);
-        if ((rc = s->tile_list.ensure(tiles ? tiles : 1))) return rc;
-        if (s->count_work) {
-            if ((rc = s->unit_cost.ensure((tiles ? tiles : 1) * 112))) return rc;
-            HIP_TRY(hipMemsetAsync(s->unit_cost.p, 0, (tiles ? tiles : 1) * 112 * sizeof(uint32_t), side));
+        const size_t tiles = frame_tiles(p);
+        if (tiles > m.tile_cap) return set_err(RT_ERR_INVALID, "frame of %zu tiles exceeds the work-list capacity %zu", tiles, m.tile_cap);
+        if (f.count_work) {
+            HIP_TRY(hipMemsetAsync(m.unit_cost, 0, tiles * 112 * sizeof(uint32_t), side));
             // layout: 16 x tiles unit slots, the four estimate features and the measured cycles of every tile of the frame,
             // then 16 x tiles unit descriptions
-            o.unit_cost = s->unit_cost.p; o.tile_cycles = s->unit_cost.p + 20 * tiles; o.unit_info = s->unit_cost.p + 21 * tiles; wk.est_by_tile = s->unit_cost.p + 16 * tiles;
+            o.unit_cost = m.unit_cost; o.tile_cycles = m.unit_cost + 20 * tiles; o.unit_info = m.unit_cost + 21 * tiles; wk.est_by_tile = m.unit_cost + 16 * tiles;
         }
-        wk.work = reinterpret_cast<uint32_t*>(s->counters.p + 24);
-        wk.cost_sum = s->counters.p + 56;          // 32 words behind the work-list words in use (work[0..63])
-        if ((rc = s->tile_cost.ensure(tiles ? tiles : 1))) return rc;
-        wk.cost = s->tile_cost.p;
-        if ((rc = s->queue_lists.ensure((tiles ? tiles : 1) * RT_QUEUE_LISTS))) return rc;
-        wk.lists = s->queue_lists.p; wk.list_cap = (uint32_t)(tiles ? tiles : 1);
+        wk.work = reinterpret_cast<uint32_t*>(m.counters + 24);
+        wk.cost_sum = m.counters + 56;          // 32 words behind the work-list words in use (work[0..63])
+        wk.cost = m.tile_cost;
+        wk.lists = m.queue_lists; wk.list_cap = (uint32_t)tiles;
         wk.thr0 = s->sched_thr0; wk.thr1 = s->sched_thr1;
         wk.n_tiles = (int32_t)tiles;
         for (int k = 0; k < 4; ++k) wk.est_w[k] = s->est_w[k];
-        wk.tile_list = s->tile_list.p;
-        // LDS for the occupancy bitmap: exact once the grid of this triangle list has been measured
-        const uint32_t cells = s->refs_known ? s->known_cells : (uint32_t)RT_MAX_CELLS;
-        wk.bitmap_words = (int32_t)((cells + 31) / 32);
+        wk.tile_list = m.tile_list;
+        // LDS for the occupancy bitmap: the grid of this triangle list was measured at upload
+        wk.bitmap_words = (int32_t)((s->known_cells + 31) / 32);
         if (wk.bitmap_words < 1) wk.bitmap_words = 1;
         wk.n_cu = s->n_cu;
         const size_t lds = rt_trace_lds_bytes(wk.bitmap_words);
         int per_cu = (int)((160 * 1024) / lds);
         wk.blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
-        { const char* e = getenv("RT_BLOCKS_PER_CU"); if (e && atoi(e) >= 1 && atoi(e) < wk.blocks_per_cu) wk.blocks_per_cu = atoi(e); }   // experiment override
-
+        if (s->blocks_per_cu_cap >= 1 && s->blocks_per_cu_cap < wk.blocks_per_cu) wk.blocks_per_cu = s->blocks_per_cu_cap;
     }
     HIP_TRY(rt_launch_render_prep(sd, cam, sh, f, wk, side));
     if (side != st) {
         HIP_TRY(hipEventRecord(s->ev_join, side));
         HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
     }
-    HIP_TRY(hipEventRecord(s->ev[slot][1], st));
+    if (ev_trace_start) HIP_TRY(hipEventRecord(ev_trace_start, st));
     HIP_TRY(rt_launch_trace(sd, cam, sh, f, o, wk, st));
+    return RT_OK;
+}
+
+extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_grid, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id, void* stream) {
+    if (!s) return set_err(RT_ERR_INVALID, "rt_render_device: NULL scene");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if ((rc = rt_scene_upload(s))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = scene_enter_stream(s, st))) return rc;
+    const bool rebuild = rebuild_grid || !s->grid_valid;
+    // working memory of the frame, grown when the triangle list or the frame size has grown
+    const size_t tiles = frame_tiles(p);
+    if ((rc = s->tile_list.ensure(tiles)) || (rc = s->tile_cost.ensure(tiles)) || (rc = s->queue_lists.ensure(tiles * RT_QUEUE_LISTS))) return rc;
+    if (s->count_work && (rc = s->unit_cost.ensure(tiles * 112))) return rc;
+    if (rebuild && (rc = scene_ensure_refs(s))) return rc;
+    const int slot = (int)(s->frames % RT_STATS_RING);
+    HIP_TRY(hipEventRecord(s->ev[slot][0], st));
+    s->built[slot] = rebuild;
+    int build = 0;
+    if (rebuild) { build = s->build_clean ? 1 : 2; s->build_clean = false; }
+    if ((rc = render_frame(s, p, scene_mem(s), build, true, d_rgb_f32, d_rgb_u8, d_hit_id, st, s->ev[slot][1]))) return rc;
+    if (rebuild) { s->grid_valid = true; s->build_clean = true; }
     HIP_TRY(hipEventRecord(s->ev[slot][2], st));
     s->frames++;
-    s->last_stream = st;
     s->last_params = *p;
-    return RT_OK;
+    return scene_leave_stream(s, st);
 }
 
 extern "C" int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id) {
@@ -696,6 +843,16 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     out->primary_rays = rows * (uint64_t)p.width;
     out->hits = c[0];
     out->shadowed = c[1];
+    return RT_OK;
+}
+
+extern "C" int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out) {
+    if (!s || !out) return set_err(RT_ERR_INVALID, "rt_scene_last_counts: bad argument");
+    if (s->frames == 0) return set_err(RT_ERR_INVALID, "no frame rendered yet");
+    memset(out, 0, sizeof(*out));
+    HIP_TRY(hipEventSynchronize(s->ev[(s->frames - 1) % RT_STATS_RING][2]));
+    unsigned long long c[24];
+    HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
     out->primary_entering = c[2]; out->steps_primary = c[3]; out->tests_primary = c[4];
     out->shadow_entering = c[5]; out->steps_shadow = c[6]; out->tests_shadow = c[7];
     out->sched_rounds = c[8]; out->sched_streams = c[9]; out->sched_lanes = c[10];
@@ -727,7 +884,7 @@ extern "C" int rt_write_ppm_u8(const char* path, const uint8_t* rgb, int32_t w, 
     return ok ? RT_OK : set_err(RT_ERR_IO, "short write to %s", path);
 }
 
-extern "C" int rt_write_ppm(const char* path, const float* rgb, int32_t w, int32_t h) {
+static int write_ppm_impl(const char* path, const float* rgb, int32_t w, int32_t h) {
     if (!path || !rgb || w <= 0 || h <= 0) return set_err(RT_ERR_INVALID, "rt_write_ppm: bad argument");
     size_t n = (size_t)w * h * 3;
     std::vector<uint8_t> b(n);
@@ -739,7 +896,9 @@ extern "C" int rt_write_ppm(const char* path, const float* rgb, int32_t w, int32
     return rt_write_ppm_u8(path, b.data(), w, h);
 }
 
-extern "C" int rt_render_ppm(rt_scene* s, const rt_params* p, const char* path) {
+extern "C" int rt_write_ppm(const char* path, const float* rgb, int32_t w, int32_t h) { RT_GUARD(int, write_ppm_impl(path, rgb, w, h)) }
+
+static int render_ppm_impl(rt_scene* s, const rt_params* p, const char* path) {
     if (!path) return set_err(RT_ERR_INVALID, "rt_render_ppm: NULL path");
     int rc = check_params(p);
     if (rc) return rc;
@@ -748,6 +907,8 @@ extern "C" int rt_render_ppm(rt_scene* s, const rt_params* p, const char* path) 
     if ((rc = rt_render(s, p, nullptr, img.data(), nullptr))) return rc;
     return rt_write_ppm_u8(path, img.data(), p->width, p->height);
 }
+
+extern "C" int rt_render_ppm(rt_scene* s, const rt_params* p, const char* path) { RT_GUARD(int, render_ppm_impl(s, p, path)) }
 
 // ------------------------------------------------------------------------------------------------
 // plane mesh generator: same OBJ text as plane_mesh_creator.py:23-80
@@ -759,7 +920,7 @@ static double py_round(double x, int ndigits) {
     return strtod(tmp, nullptr);
 }
 
-extern "C" int rt_make_plane_obj(const char* path, int32_t squares_per_unit) {
+static int make_plane_obj_impl(const char* path, int32_t squares_per_unit) {
     if (!path || squares_per_unit < 1) return set_err(RT_ERR_INVALID, "rt_make_plane_obj: bad argument");
     const int round_amount = (int)log10((double)squares_per_unit);        // plane_mesh_creator.py:20
     const double step = 1.0 / squares_per_unit;                           // :21
@@ -803,3 +964,5 @@ extern "C" int rt_make_plane_obj(const char* path, int32_t squares_per_unit) {
     ok = (fclose(f) == 0) && ok;
     return ok ? RT_OK : set_err(RT_ERR_IO, "write to %s failed", path);
 }
+
+extern "C" int rt_make_plane_obj(const char* path, int32_t squares_per_unit) { RT_GUARD(int, make_plane_obj_impl(path, squares_per_unit)) }

@@ -1759,12 +1759,15 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
         WalkCount wp = {}, ws = {};
         const long long t_start = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const unsigned long long rt_start = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        const bool hit = wave_walk<false, true, COUNT, OWN>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
+        const bool hit_any = wave_walk<false, true, COUNT, OWN>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
                                                        sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, per_unit, st, wp);
         float cr = 0.f, cg = 0.f, cb = 0.f;
         float colr = 0.f, colg = 0.f, colb = 0.f;
         float poix = 0.f, poiy = 0.f, poiz = 0.f, sx = 0.f, sy = 0.f, sz = 1.f;
         int id = -1;
+        // A triangle can pass the barycentric test with a hit distance that is NaN or +inf (overflowing coordinates): the
+        // reference then shades whatever triangle an earlier pixel left in its global; here such a pixel stays background.
+        const bool hit = hit_any && st.id >= 0;
         if (hit) {
             id = st.id;
             const float4 p0 = s.v0[id], p1 = s.v1[id], p2 = s.v2[id];

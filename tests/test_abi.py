@@ -13,7 +13,7 @@ from conftest import BLUB, GOLDEN, ROOT, SPOT, bits
 
 
 def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    text = open(os.path.join(ROOT, "include", "rt_amd.h")).read() + open(os.path.join(ROOT, "include", "rt_amd_diag.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
 
