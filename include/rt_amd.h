@@ -110,6 +110,18 @@ int rt_scene_get_csr(rt_scene* s, uint32_t* cell_start, uint32_t* cell_tris);
  * pointers may be NULL. d_rgb_f32: 3 floats per pixel (the Vec3f image of :141), d_rgb_u8: the PPM
  * body bytes of :181-183, d_hit_id: primary-hit triangle index or -1. Row-major, rt_part_rows() rows. */
 int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_grid, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id, void* stream);
+/* rt_render_device() for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc. No counterpart in the reference. The call allocates nothing, neither on the device nor
+ * through any allocating library routine: the working memory of the frame (grid description, voxel tables, reference
+ * lists, triangle records in voxel order, run bounds, work lists, counters) is a fixed array of about 32 MB that every GPU
+ * the library runs on holds until the process ends. It issues kernels and memsets on `stream` only (no events, no second
+ * stream, no host synchronisation) and rebuilds the grid on every call. The scene's triangles must already be on the
+ * device: call rt_scene_upload() once, outside the code that cannot allocate. Limits, rejected with RT_ERR_INVALID and a
+ * message: 524,288 (voxel, triangle) references in the scene's grid; 32,640 tiles of 8x8 pixels in the output buffers
+ * (1920 x 1088 pixels). All calls on one GPU share the one array, which keeps the last call's contents: calls that overlap
+ * in time on one GPU (two streams, two threads) race; calls on one stream, or ordered by the caller, are safe, also for
+ * different scenes. No frame statistics are recorded for these frames. */
+int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id, void* stream);
 /* Host-buffer variant (uploads if needed, renders, copies back, synchronises). Buffers may be NULL. */
 int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id);
 /* render() including its file output: writes "P6\nW H\n255\n" + body to `path` ("./test.ppm" in the reference). */

@@ -113,6 +113,39 @@ struct RtBuildDev {
     unsigned long long* counters;
 };
 
+// Fixed working memory of rt_render_device_noalloc(): one device array per GPU (file scope in rt_kernels.hip), carved
+// into the buffers of a frame at 256-byte boundaries. Limits: references of the grid, 8x8 tiles of the frame.
+#define RT_NOALLOC_MAX_REFS 524288u
+#define RT_NOALLOC_MAX_TILES 32640u                // 1920 x 1088 pixels
+struct RtNoallocLayout {
+    size_t grid, bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell, row_minmax, recs, blk_bounds, counters, tile_list,
+        tile_cost, queue_lists, total;
+};
+constexpr size_t rt_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr RtNoallocLayout rt_noalloc_layout() {
+    RtNoallocLayout L{};
+    size_t o = 0;
+    L.grid = o; o += rt_align256(sizeof(RtGrid));
+    L.bounds_enc = o; o += rt_align256(8 * sizeof(uint32_t));
+    L.cell_count = o; o += rt_align256((size_t)RT_MAX_CELLS * sizeof(uint32_t));
+    L.cell_start = o; o += rt_align256(((size_t)RT_MAX_CELLS + 1) * sizeof(uint32_t));
+    L.block_sums = o; o += rt_align256((size_t)RT_MAX_SCAN_BLOCKS * sizeof(uint32_t));
+    L.occupancy = o; o += rt_align256(((size_t)RT_MAX_CELLS / 32 + 2) * sizeof(uint32_t));
+    L.ref_tri = o; o += rt_align256((size_t)RT_NOALLOC_MAX_REFS * sizeof(uint32_t));
+    L.ref_cell = o; o += rt_align256((size_t)RT_NOALLOC_MAX_REFS * sizeof(uint32_t));
+    L.row_minmax = o; o += rt_align256(((size_t)RT_NOALLOC_MAX_REFS / 64 + 2) * sizeof(uint2));
+    L.recs = o; o += rt_align256((size_t)RT_NOALLOC_MAX_REFS * 3 * sizeof(float4));
+    L.blk_bounds = o; o += rt_align256(((size_t)RT_NOALLOC_MAX_REFS / 64 + 2) * 3 * sizeof(float4));
+    L.counters = o; o += rt_align256(88 * sizeof(unsigned long long));
+    L.tile_list = o; o += rt_align256((size_t)RT_NOALLOC_MAX_TILES * sizeof(uint32_t));
+    L.tile_cost = o; o += rt_align256((size_t)RT_NOALLOC_MAX_TILES * sizeof(uint32_t));
+    L.queue_lists = o; o += rt_align256((size_t)RT_NOALLOC_MAX_TILES * RT_QUEUE_LISTS * sizeof(uint32_t));
+    L.total = o;
+    return L;
+}
+// Device address of that array on the current device (looked up once per device).
+hipError_t rt_noalloc_scratch(void** ptr);
+
 // Launch wrappers (rt_kernels.hip). All asynchronous on `st`; they return the hipGetLastError() of their launches.
 hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh, RtBuildDev b, hipStream_t st);
 // bounds + set-up, count, scan -> grid.n_refs known. `first`: the scene's build state has not been left behind clean by a

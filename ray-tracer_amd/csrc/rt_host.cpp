@@ -365,7 +365,8 @@ static int scene_bind_device(rt_scene* s) {
 }
 
 // Working memory of a frame: everything the grid build and the render kernels write besides the caller's outputs.
-// A scene owns one set (allocated on demand, reused by later frames).
+// A scene owns one set (allocated on demand, reused by later frames); rt_render_device_noalloc() uses a set carved out
+// of a fixed device array instead.
 struct FrameMem {
     RtGrid* grid = nullptr;
     uint32_t *bounds_enc = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr, *occupancy = nullptr;
@@ -747,6 +748,46 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     s->frames++;
     s->last_params = *p;
     return scene_leave_stream(s, st);
+}
+
+// Variant of rt_render_device() that allocates nothing: the working memory of the frame (grid, voxel tables, reference
+// lists, triangle records in voxel order, run bounds, work lists, counters) is a fixed device array inside the library
+// instead of buffers the scene allocates. The triangle arrays of the scene must already be on the device
+// (rt_scene_upload, which also measures the reference count the limit is checked against). The grid is rebuilt on
+// every call, because the array keeps whatever the last call on this GPU left there, of this scene or another one.
+extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id, void* stream) {
+    if (!s) return set_err(RT_ERR_INVALID, "rt_render_device_noalloc: NULL scene");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!s->uploaded || s->device < 0 || !s->refs_known)
+        return set_err(RT_ERR_INVALID, "rt_render_device_noalloc: call rt_scene_upload() first (this entry point allocates nothing)");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != s->device) return set_err(RT_ERR_INVALID, "scene is bound to device %d, current device is %d", s->device, dev);
+    if (s->known_refs > RT_NOALLOC_MAX_REFS)
+        return set_err(RT_ERR_INVALID, "rt_render_device_noalloc: the grid of this scene has %u (voxel, triangle) references, the fixed working memory holds %u",
+                       s->known_refs, (unsigned)RT_NOALLOC_MAX_REFS);
+    const size_t tiles = frame_tiles(p);
+    if (tiles > RT_NOALLOC_MAX_TILES)
+        return set_err(RT_ERR_INVALID, "rt_render_device_noalloc: a frame of %d x %d pixels has %zu tiles of 8x8, the fixed working memory holds %u",
+                       p->width, rt_part_rows(p), tiles, (unsigned)RT_NOALLOC_MAX_TILES);
+    void* base_v = nullptr;
+    HIP_TRY(rt_noalloc_scratch(&base_v));
+    unsigned char* base = (unsigned char*)base_v;
+    constexpr RtNoallocLayout L = rt_noalloc_layout();
+    FrameMem m;
+    m.grid = (RtGrid*)(base + L.grid); m.bounds_enc = (uint32_t*)(base + L.bounds_enc);
+    m.cell_count = (uint32_t*)(base + L.cell_count); m.cell_start = (uint32_t*)(base + L.cell_start);
+    m.block_sums = (uint32_t*)(base + L.block_sums); m.occupancy = (uint32_t*)(base + L.occupancy);
+    m.ref_tri = (uint32_t*)(base + L.ref_tri); m.ref_cell = (uint32_t*)(base + L.ref_cell); m.row_minmax = (uint2*)(base + L.row_minmax);
+    m.recs = (float4*)(base + L.recs); m.blk_bounds = (float4*)(base + L.blk_bounds);
+    m.ref_cap = RT_NOALLOC_MAX_REFS;
+    m.counters = (unsigned long long*)(base + L.counters);
+    m.tile_list = (uint32_t*)(base + L.tile_list); m.tile_cost = (uint32_t*)(base + L.tile_cost); m.queue_lists = (uint32_t*)(base + L.queue_lists);
+    m.tile_cap = RT_NOALLOC_MAX_TILES;
+    m.unit_cost = nullptr;
+    // one stream, no events, no side stream: kernels and memsets only
+    return render_frame(s, p, m, 2, false, d_rgb_f32, d_rgb_u8, d_hit_id, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id) {

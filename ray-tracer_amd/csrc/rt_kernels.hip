@@ -7,6 +7,8 @@
 #include <limits.h>
 #include <math.h>
 
+#include <mutex>
+
 #define RT_TILE 8                     // a wavefront renders one 8x8 pixel tile
 #define RT_BLOCK_THREADS 256
 
@@ -1923,6 +1925,34 @@ hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, Rt
 
 size_t rt_trace_lds_bytes(int bitmap_words) {
     return (size_t)bitmap_words * 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fixed working memory of rt_render_device_noalloc()
+// ------------------------------------------------------------------------------------------------
+// Every GPU the library runs on holds its own copy of this array (about 32 MB) until the process ends. In host code the
+// array's name is only a handle for hipGetSymbolAddress, not an address a kernel could use: the device address is looked
+// up once per device, with that device current, and that pointer is what kernels and memsets get.
+static __device__ __align__(256) unsigned char scratch[rt_noalloc_layout().total];
+
+#define RT_MAX_DEVICES 64
+hipError_t rt_noalloc_scratch(void** ptr) {
+    static std::mutex mu;
+    static void* per_device[RT_MAX_DEVICES] = {};
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= RT_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        per_device[dev] = p;
+    }
+    *ptr = per_device[dev];
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------------
