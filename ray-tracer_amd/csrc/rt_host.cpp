@@ -97,7 +97,7 @@ struct rt_scene {
     // wavefront and "cheap" below 1/thr1 of it; unit_shifts holds log2 of the work units a tile is cut into, 4 bits per
     // queue list (expensive 0..7 from the top down, cheap 8..11, in-between 12..15)
     float sched_thr0 = 1.f, sched_thr1 = 4.f;
-    uint64_t sched_shifts = 0x2222000022223333ull;
+    uint64_t sched_shifts = 0x2222000011112222ull;
     bool sched_adapt = true;               // off when RT_SHIFTS gives the unit sizes explicitly
     float est_w[4] = {1.f, 500.f, 0.f, 700.f};    // cost estimate weights: primary triangles, primary voxels, shadow triangles, shadow voxels
     hipStream_t last_stream = nullptr;       // stream of the last frame or grid build (build state is shared between frames)
@@ -133,7 +133,7 @@ extern "C" rt_scene* rt_scene_create(void) {
         if (const char* e = getenv("RT_SHIFTS")) {
             char* end = nullptr;
             const unsigned long long v = strtoull(e, &end, 16);
-            bool ok = end && *end == 0;
+            bool ok = end && end != e && *end == 0;          // an empty value is no override
             for (int k = 0; k < 16 && ok; ++k) ok = ((v >> (4 * k)) & 15ull) <= 4;
             if (ok) { s->sched_shifts = v; s->sched_adapt = false; }
         }

@@ -1086,17 +1086,19 @@ __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if (blockIdx.x * blockDim.x >= n) return;
-    // Unit sizes of the lists, for k_trace. The given sizes suit frames with about one listed tile per wavefront; with
-    // more tiles per wavefront there are enough units to balance the load anyway, and larger units are cheaper (the
-    // stepping, culling and shading of a unit cost the same for 16 rays as for 64): one size up from 2.5 tiles per
-    // wavefront, two from 10. In a sparse grid (fewer than two references per voxel on average) most voxels hold a
-    // handful of triangles that the rays test themselves, lane = ray, at a cost that does not depend on the rays of the
-    // unit at all: there the units of the expensive lists are one size larger as well.
+    // Unit sizes of the lists, for k_trace. The given sizes suit frames with up to about two listed tiles per wavefront (a
+    // rank's share of a frame on several GPUs): there the frame time is the run time of its longest units, and the
+    // expensive and the in-between tiles are cut into units of 16 and 32 rays. With more tiles per wavefront there are
+    // enough units to balance the load anyway, and larger units are cheaper (the stepping, culling and shading of a unit
+    // cost the same for 16 rays as for 64): the in-between lists go one size up from 2.5 tiles per wavefront and two from
+    // 10, the expensive lists follow one step later. In a sparse grid (fewer than two references per voxel on average)
+    // most voxels hold a handful of triangles that the rays test themselves, lane = ray, at a cost that does not depend on
+    // the rays of the unit at all: there the expensive lists go up together with the others.
     if (blockIdx.x == 0 && threadIdx.x < RT_QUEUE_LISTS) {
         uint32_t sh = (uint32_t)((unit_shifts >> (4 * threadIdx.x)) & 15ull);
         if (adapt) {
             uint32_t up = (2u * n >= 5u * (uint32_t)n_waves ? 1u : 0u) + (n >= 10u * (uint32_t)n_waves ? 1u : 0u);
-            if (threadIdx.x < 8 && grid->n_refs < 2u * grid->n_cells) up += 1u;
+            if (threadIdx.x < 8 && !(grid->n_refs < 2u * grid->n_cells)) up = up > 0u ? up - 1u : 0u;
             sh = sh > up ? sh - up : 0u;
         }
         work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + threadIdx.x] = sh;
@@ -1205,6 +1207,36 @@ hipError_t rt_launch_selftest_div(const double* num, const double* den, uint32_t
     return hipGetLastError();
 }
 
+// Order-free form of the reference's nearest-hit update. Triangle::Intersect (Serial/geometry.h:162-175) compares the
+// double hit distance t_c of every passing triangle with the FLOAT global_t and stores (float)t_c, so the outcome of a
+// voxel's tests depends on their order (ascending triangle index, Serial/grid.h:24-29) through that rounding. The
+// dependence has a closed form. With fl() the rounding to float, for the passing triangles c of ONE voxel visit let
+//     f  = min over c of fl(t_c),    j0 = the smallest index with fl(t_c) == f,
+//     L  = the largest index with fl(t_c) == f and t_c < f (compared as doubles), if there is one.
+// Going through the candidates in ascending index from a state (t, id): the first candidate that rounds to f sets
+// t = f (fl is monotonic, so t_c < t exactly when fl(t_c) < t or fl(t_c) == t and t_c < t), nothing that rounds to more
+// than f can follow it, and every later candidate that rounds to f but lies below it as a double takes the index over.
+// Hence after the visit
+//     t > f :  (t, id) = (f, L if it exists, else j0);     t == f :  id = L if it exists;     t < f :  unchanged.
+// (f, j0, L) can be accumulated in any order, so a voxel's records need no particular order in memory and its runs
+// can be tested in any order. tests/test_merge_rule.py checks the rule against the sequential loop.
+struct VoxelBest {
+    float f;
+    uint32_t j0;
+    int L;
+};
+__device__ __forceinline__ void vb_reset(VoxelBest& v) { v.f = INFINITY; v.j0 = 0xffffffffu; v.L = -1; }
+__device__ __forceinline__ void vb_add(VoxelBest& v, double t, int id) {
+    const float fj = (float)t;                           // NaN: both comparisons fail, like t_c < global_t
+    const int below = (t < (double)fj) ? id : -1;
+    if (fj < v.f) { v.f = fj; v.j0 = (uint32_t)id; v.L = below; }
+    else if (fj == v.f) { v.j0 = min(v.j0, (uint32_t)id); v.L = max(v.L, below); }
+}
+__device__ __forceinline__ void vb_apply(const VoxelBest& v, Nearest& st) {
+    if (v.f < st.t) { st.t = v.f; st.id = (v.L >= 0) ? v.L : (int)v.j0; }
+    else if (v.f == st.t && v.L >= 0) st.id = v.L;
+}
+
 // One triangle record as a lane holds it during the test phase.
 struct TriRec {
     float v0x, v0y, v0z;
@@ -1259,9 +1291,10 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 //         therefore loaded once per voxel visit of the work unit, not once per ray, and lane utilisation is the
 //         run's fill, whatever the number of rays sharing it.
 //         The reference tests a voxel's triangles in ascending index and updates (global_t, nearest triangle)
-//         after each one; here the runs are visited in ascending order and the passing lanes of a run are applied in
-//         ascending lane order, which is the same order, so the float rounding of global_t between updates is
-//         reproduced.
+//         after each one; the float rounding of global_t between those updates makes the outcome depend on the
+//         order. Here every ray collects the passing triangles of its voxel in an order-free summary (VoxelBest)
+//         and applies it to its state when the voxel is done, which gives the reference's outcome whatever the
+//         order of the records and of the runs.
 //
 // Triangle::Intersect (Serial/geometry.h:131-177): the four 3x3 determinants share their 2x2 minors over the
 // y,z rows; evaluating each minor once changes no bit because negating a minor is exact and the t1 - t2 + t3
@@ -1326,6 +1359,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         const uint32_t org = cull ? (cbeg & ~63u) : cbeg;
         const uint32_t nrun_me = (cend - org + 63u) >> 6;
         unsigned long long need0 = ~0ull, need1 = ~0ull, any0 = ~0ull, any1 = ~0ull;
+        VoxelBest vb;                                    // passing triangles of this round's voxel (primary rays)
+        vb_reset(vb);
         // FP32 test of a ray's whole line against a run's box and slab (k_block_bounds): the parameter interval in which
         // the line is inside the box must overlap the one in which it is between the slab's planes. Box faces and slab
         // planes are moved outwards by mg = 4e-6 (8e-6 for the slab) * (largest |coordinate| of the box + |origin|), more
@@ -1455,9 +1490,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                                     const double t_g = __shfl(t_p, src);
                                     if (id_g >= 0 && g == 0 && own) {
                                         hit = true;
-                                        if (t_g < (double)st.t) {
-                                            if (!use_eps || t_g > (double)eps) { st.t = (float)t_g; st.id = id_g; }
-                                        }
+                                        if (!use_eps || t_g > (double)eps) vb_add(vb, t_g, id_g);
                                     }
                                 }
                             }
@@ -1491,9 +1524,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                         }
                         const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
                         const double t_p = tnum / A;
-                        if (t_p < (double)st.t) {
-                            if (!use_eps || t_p > (double)eps) { st.t = (float)t_p; st.id = (int)t.id; }
-                        }
+                        if (!use_eps || t_p > (double)eps) vb_add(vb, t_p, (int)t.id);
                     }
                 }
                 if (COUNT) {                     // tests executed: a wavefront-wide number like the streamed runs' lanes
@@ -1628,17 +1659,13 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                             }
                         } else {
                             if (lane == i) hit = true;
-                            // apply the passing triangles in ascending lane order = ascending triangle order
+                            // the passing triangles go into the ray's summary of this voxel visit (any order)
                             while (pm) {
                                 const int pl = __ffsll((long long)pm) - 1;
                                 pm &= pm - 1;
                                 const double t_p = bcast_f64(tt, pl);
                                 const int id_p = __builtin_amdgcn_readlane((int)t.id, pl);
-                                if (lane == i) {
-                                    if (t_p < (double)st.t) {
-                                        if (!use_eps || t_p > (double)eps) { st.t = (float)t_p; st.id = id_p; }
-                                    }
-                                }
+                                if (lane == i && (!use_eps || t_p > (double)eps)) vb_add(vb, t_p, id_p);
                             }
                         }
                     }
@@ -1668,6 +1695,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 process(cur, t);
             }
         }
+        if (!ANY_HIT) vb_apply(vb, st);
         if (COUNT) wc.cyc_test += (uint32_t)((long long)__builtin_amdgcn_s_memtime() - t2);
     }
     return hit;

@@ -196,7 +196,7 @@ def test_unit_sizes_and_cost_classes_do_not_change_the_image(rt, plane10, monkey
 
 
 @pytest.mark.parametrize("own", ["0", "1"])
-@pytest.mark.parametrize("shifts", [None, "0000000000000000", "1111111111111111", "3333333333333333"])
+@pytest.mark.parametrize("shifts", [None, "0000000000000000", "1111111111111111", "2222222222222222", "3333333333333333", "4444444444444444"])
 def test_both_trace_kernels_give_the_golden_image(rt, plane10, monkeypatch, own, shifts):
     """The trace kernel exists with and without the lane = ray path for voxels of a few records (the library picks by
     the grid's reference count); with it, units of 64 rays test serially and smaller units share a voxel's records
