@@ -27,6 +27,10 @@ typedef struct rt_frame_counts {
 
 /* Work accounting: when enabled, frames also count voxel steps and triangle tests per ray class. */
 int rt_scene_set_counting(rt_scene* s, int32_t enable);
+/* What rt_scene_upload() measured to choose the order of the records inside a voxel: the summed surface area of the
+ * bounds of all runs of 64 records with the records as the scatter leaves them (area[0]) and in ascending triangle index
+ * (area[1]; both 0 when nothing was measured: small meshes, RT_SORTED_BUILD set), and whether frames sort (1) or not (0). */
+int rt_scene_record_order(rt_scene* s, double area[2], int32_t* sorted);
 /* Counters of the last frame (zeros unless it was a counting frame); synchronises the device. */
 int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out);
 /* Diagnostics of the last counting frame, as 32-bit words; with t = tiles of the frame (8x8 pixels each):

@@ -71,7 +71,7 @@ EXPORTS = [
     "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
-    "rt_render_device", "rt_render_device_noalloc", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_unit_costs",
+    "rt_render_device", "rt_render_device_noalloc", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_unit_costs",
     "rt_deinterleave_device", "rt_selftest_division",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
@@ -120,6 +120,7 @@ def lib():
     L.rt_scene_stats_at.argtypes = [vp, i32, vp]
     L.rt_scene_set_counting.argtypes = [vp, i32]
     L.rt_scene_last_counts.argtypes = [vp, vp]
+    L.rt_scene_record_order.argtypes = [vp, vp, vp]
     L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
     L.rt_render_device_noalloc.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rt_deinterleave_device.argtypes = [vp, vp, vp, i32, vp]
@@ -246,6 +247,12 @@ class Scene:
     def render_device_noalloc(self, params, d_rgb=None, d_u8=None, d_ids=None, stream=None):
         """rt_render_device_noalloc: the frame's working memory is the library's fixed device array."""
         _check(lib().rt_render_device_noalloc(self.h, C.byref(params), d_rgb, d_u8, d_ids, stream))
+
+    def record_order(self):
+        """(area unsorted, area sorted, frames sort?) as measured by upload(); see rt_scene_record_order."""
+        a, srt = (C.c_double * 2)(), C.c_int32()
+        _check(lib().rt_scene_record_order(self.h, a, C.byref(srt)))
+        return a[0], a[1], bool(srt.value)
 
     def unit_costs(self, n):
         out = np.zeros(n, np.uint32)

@@ -111,6 +111,8 @@ struct RtBuildDev {
     float4* blk_bounds;           // 3 * (ref_cap / 64 + 2)
     uint32_t ref_cap;
     unsigned long long* counters;
+    int32_t sorted;               // 1: voxel lists in ascending triangle index (scatter, row sort, ranking; needs ref_tri, ref_cell,
+                                  // row_minmax); 0: records scattered straight into their voxels, in no particular order
 };
 
 // Fixed working memory of rt_render_device_noalloc(): one device array per GPU (file scope in rt_kernels.hip), carved
@@ -118,7 +120,7 @@ struct RtBuildDev {
 #define RT_NOALLOC_MAX_REFS 524288u
 #define RT_NOALLOC_MAX_TILES 32640u                // 1920 x 1088 pixels
 struct RtNoallocLayout {
-    size_t grid, bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell, row_minmax, recs, blk_bounds, counters, tile_list,
+    size_t grid, bounds_enc, cell_count, cell_start, block_sums, occupancy, recs, blk_bounds, counters, tile_list,
         tile_cost, queue_lists, total;
 };
 constexpr size_t rt_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -131,9 +133,6 @@ constexpr RtNoallocLayout rt_noalloc_layout() {
     L.cell_start = o; o += rt_align256(((size_t)RT_MAX_CELLS + 1) * sizeof(uint32_t));
     L.block_sums = o; o += rt_align256((size_t)RT_MAX_SCAN_BLOCKS * sizeof(uint32_t));
     L.occupancy = o; o += rt_align256(((size_t)RT_MAX_CELLS / 32 + 2) * sizeof(uint32_t));
-    L.ref_tri = o; o += rt_align256((size_t)RT_NOALLOC_MAX_REFS * sizeof(uint32_t));
-    L.ref_cell = o; o += rt_align256((size_t)RT_NOALLOC_MAX_REFS * sizeof(uint32_t));
-    L.row_minmax = o; o += rt_align256(((size_t)RT_NOALLOC_MAX_REFS / 64 + 2) * sizeof(uint2));
     L.recs = o; o += rt_align256((size_t)RT_NOALLOC_MAX_REFS * 3 * sizeof(float4));
     L.blk_bounds = o; o += rt_align256(((size_t)RT_NOALLOC_MAX_REFS / 64 + 2) * 3 * sizeof(float4));
     L.counters = o; o += rt_align256(88 * sizeof(unsigned long long));
@@ -151,6 +150,7 @@ hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh,
 // bounds + set-up, count, scan -> grid.n_refs known. `first`: the scene's build state has not been left behind clean by a
 // completed build (k_build_init runs)
 hipError_t rt_launch_build_phase1(RtBuildDev b, bool first, hipStream_t st);
+hipError_t rt_launch_run_area(RtBuildDev b, double* out, hipStream_t st);   // adds the summed surface area of the run boxes to *out
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st);   // scatter, per-cell order, record emit
 hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtRenderWork wk, hipStream_t st);   // classify, estimate, cost classes
 hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st);

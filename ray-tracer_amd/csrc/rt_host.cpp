@@ -112,6 +112,14 @@ struct rt_scene {
     int cull_min = 64, cull_lane_runs = 12;
     int blocks_per_cu_cap = 0;
     size_t n_tris() const { return tri_mesh.size(); }
+    // Voxel lists in ascending triangle index are only needed where the order shows: the counting build of the render kernel
+    // (its shadow-ray test counts are those of the reference's order) and the read-back of the lists. RT_SORTED_BUILD=1
+    // forces it, for experiments.
+    int force_sorted = -1;                   // RT_SORTED_BUILD: 0 / 1 force a build mode, -1 = the library decides
+    bool prefer_sorted = false;              // measured once per triangle list (scene_choose_record_order)
+    double run_area[2] = {0, 0};             // what was measured: summed run-box areas, unsorted and sorted
+    bool grid_sorted = false;                // how the current grid was built
+    bool want_sorted() const { return count_work || (force_sorted >= 0 ? force_sorted != 0 : prefer_sorted); }
 };
 
 static int env_int(const char* name, int lo, int hi, int dflt) {
@@ -141,6 +149,7 @@ extern "C" rt_scene* rt_scene_create(void) {
         s->cull_min = env_int("RT_CULL_MIN", 1, 65535, 64);
         s->cull_lane_runs = env_int("RT_CULL_LANE_RUNS", 0, 64, 12);
         s->blocks_per_cu_cap = env_int("RT_BLOCKS_PER_CU", 1, 64, 0);
+        s->force_sorted = env_int("RT_SORTED_BUILD", 0, 1, -1);
     }
     return s;
 }
@@ -373,7 +382,8 @@ struct FrameMem {
     uint32_t *ref_tri = nullptr, *ref_cell = nullptr;
     uint2* row_minmax = nullptr;
     float4 *recs = nullptr, *blk_bounds = nullptr;
-    size_t ref_cap = 0;                      // references the five arrays above can hold
+    size_t ref_cap = 0;                      // references recs and blk_bounds can hold
+    bool sorted = false;                     // build the voxel lists in ascending triangle index (needs ref_tri, ref_cell, row_minmax)
     unsigned long long* counters = nullptr;  // RT_COUNTER_WORDS
     uint32_t *tile_list = nullptr, *tile_cost = nullptr, *queue_lists = nullptr;
     size_t tile_cap = 0;                     // tiles the three lists above can hold (queue_lists: RT_QUEUE_LISTS times as many)
@@ -386,7 +396,8 @@ static FrameMem scene_mem(rt_scene* s) {
     m.grid = s->d_grid.p; m.bounds_enc = s->bounds_enc.p; m.cell_count = s->cell_count.p; m.cell_start = s->cell_start.p;
     m.block_sums = s->block_sums.p; m.occupancy = s->occupancy.p;
     m.ref_tri = s->ref_tri.p; m.ref_cell = s->ref_cell.p; m.row_minmax = s->row_minmax.p; m.recs = s->recs.p; m.blk_bounds = s->blk_bounds.p;
-    m.ref_cap = s->ref_tri.cap;
+    m.ref_cap = s->recs.cap / 3;
+    m.sorted = s->want_sorted();
     m.counters = s->counters.p;
     m.tile_list = s->tile_list.p; m.tile_cost = s->tile_cost.p; m.queue_lists = s->queue_lists.p; m.tile_cap = s->tile_list.cap;
     m.unit_cost = s->unit_cost.p;
@@ -404,6 +415,7 @@ static RtBuildDev build_args(rt_scene* s, const FrameMem& m) {
     b.ref_tri = m.ref_tri; b.ref_cell = m.ref_cell; b.row_minmax = m.row_minmax; b.recs = m.recs; b.blk_bounds = m.blk_bounds;
     b.ref_cap = (uint32_t)m.ref_cap;
     b.counters = m.counters;
+    b.sorted = m.sorted ? 1 : 0;
     return b;
 }
 
@@ -434,6 +446,44 @@ static int scene_measure_grid(rt_scene* s) {
     s->refs_known = true;
     s->build_clean = false;      // the count was not consumed by a scatter
     s->grid_valid = false;
+    return RT_OK;
+}
+
+static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStream_t st, hipEvent_t after_phase1);
+
+// Which order of the records inside a voxel: the default build leaves them in the order the scatter's atomics hand the
+// places out, which costs nothing; ascending triangle index costs a sort and a ranking pass per build. The order never
+// changes the image, but the render kernel culls whole runs of 64 consecutive records by their bounds, and how tight those
+// bounds are depends on which triangles share a run. For a mesh whose voxels collect their triangles from many separate
+// index ranges (the generated plane: 17 strips per voxel, two thousand indices apart) the atomics shuffle those ranges
+// and the runs get several times larger than in index order; for others (subdivided meshes) it makes no difference. So
+// both builds run once per triangle list, the summed surface area of the run boxes is compared (the number of runs a ray
+// meets is proportional to it), and the sort is kept only where it buys tighter runs. Synchronous, part of the upload.
+static int scene_choose_record_order(rt_scene* s) {
+    s->prefer_sorted = false;
+    s->run_area[0] = s->run_area[1] = 0;
+    if (s->force_sorted >= 0 || s->n_tris() <= 65536 || s->known_refs == 0) return RT_OK;      // small meshes: voxels too small for run culling
+    int rc;
+    const size_t need = s->known_refs;
+    if ((rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(3 * (need / 64 + 2))) || (rc = s->ref_tri.ensure(need)) ||
+        (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)))
+        return rc;
+    DevBuf<double> d_area;
+    if ((rc = d_area.ensure(2))) return rc;
+    hipError_t e = hipMemset(d_area.p, 0, 2 * sizeof(double));
+    for (int mode = 1; mode >= 0 && e == hipSuccess; --mode) {        // sorted first, so that the unsorted grid is the one left behind
+        FrameMem m = scene_mem(s);
+        m.sorted = mode == 1;
+        if (build_grid_async(s, m, true, nullptr, nullptr)) { d_area.release(); return RT_ERR_HIP; }
+        e = rt_launch_run_area(build_args(s, m), d_area.p + mode, nullptr);
+    }
+    if (e == hipSuccess) e = hipMemcpy(s->run_area, d_area.p, 2 * sizeof(double), hipMemcpyDeviceToHost);
+    d_area.release();
+    if (e != hipSuccess) return set_err(RT_ERR_HIP, "record order measurement: %s", hipGetErrorString(e));
+    s->prefer_sorted = s->run_area[0] > 1.10 * s->run_area[1];
+    if (!s->prefer_sorted) { s->ref_tri.release(); s->ref_cell.release(); s->row_minmax.release(); }
+    s->grid_valid = false;
+    s->build_clean = false;
     return RT_OK;
 }
 
@@ -472,13 +522,14 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     s->grid_valid = false;
     s->build_clean = false;
     s->refs_known = false;
-    return scene_measure_grid(s);
+    if ((rc = scene_measure_grid(s))) return rc;
+    return scene_choose_record_order(s);
 }
 
 // Grid build on the working memory `m`. `first`: the build counters in `m` have not been left reset by a completed
 // build (k_build_init runs). `after_phase1`, when given, is recorded once cell_start and the occupancy bitmap are final
 // (the records are not yet).
-static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStream_t st, hipEvent_t after_phase1 = nullptr) {
+static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStream_t st, hipEvent_t after_phase1) {
     if ((size_t)s->known_refs > m.ref_cap) return set_err(RT_ERR_INVALID, "grid build: %u references exceed the capacity %zu", s->known_refs, m.ref_cap);
     HIP_TRY(rt_launch_build_phase1(build_args(s, m), first, st));
     if (after_phase1) HIP_TRY(hipEventRecord(after_phase1, st));
@@ -490,9 +541,8 @@ static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStrea
 static int scene_ensure_refs(rt_scene* s) {
     int rc;
     const size_t need = s->known_refs ? s->known_refs : 1;
-    if ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)) ||
-        (rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(3 * (need / 64 + 2))))
-        return rc;
+    if ((rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(3 * (need / 64 + 2)))) return rc;
+    if (s->want_sorted() && ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)))) return rc;
     return RT_OK;
 }
 
@@ -504,6 +554,7 @@ static int scene_build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_
     if ((rc = build_grid_async(s, scene_mem(s), first, st, after_phase1))) return rc;
     s->grid_valid = true;
     s->build_clean = true;
+    s->grid_sorted = s->want_sorted();
     return RT_OK;
 }
 
@@ -537,6 +588,15 @@ extern "C" int rt_scene_get_grid(rt_scene* s, int32_t n[3], float lohi[6], float
 extern "C" int rt_scene_get_csr(rt_scene* s, uint32_t* cell_start, uint32_t* cell_tris) {
     if (!s || !s->grid_valid) return set_err(RT_ERR_INVALID, "rt_scene_get_csr: grid not built");
     HIP_TRY(hipDeviceSynchronize());
+    if (!s->grid_sorted) {
+        // the lists are read back in the reference's order: build them that way once more
+        const int forced = s->force_sorted;
+        s->force_sorted = 1;
+        int rc = scene_build_grid_async(s, nullptr);
+        s->force_sorted = forced;
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());      // (a later frame rebuilds in its own mode if that differs)
+    }
     RtGrid g;
     HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
     if (cell_start) HIP_TRY(hipMemcpy(cell_start, s->cell_start.p, ((size_t)g.n_cells + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -631,7 +691,7 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
             HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
         }
     } else if (build != 0) {
-        if ((rc = build_grid_async(s, m, build == 2, st))) return rc;
+        if ((rc = build_grid_async(s, m, build == 2, st, nullptr))) return rc;
     }
     const bool counting = s->count_work && m.unit_cost;
     HIP_TRY(hipMemsetAsync(m.counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), side));
@@ -731,7 +791,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     if ((rc = rt_scene_upload(s))) return rc;
     hipStream_t st = (hipStream_t)stream;
     if ((rc = scene_enter_stream(s, st))) return rc;
-    const bool rebuild = rebuild_grid || !s->grid_valid;
+    const bool rebuild = rebuild_grid || !s->grid_valid || s->grid_sorted != s->want_sorted();
     // working memory of the frame, grown when the triangle list or the frame size has grown
     const size_t tiles = frame_tiles(p);
     if ((rc = s->tile_list.ensure(tiles)) || (rc = s->tile_cost.ensure(tiles)) || (rc = s->queue_lists.ensure(tiles * RT_QUEUE_LISTS))) return rc;
@@ -743,7 +803,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     int build = 0;
     if (rebuild) { build = s->build_clean ? 1 : 2; s->build_clean = false; }
     if ((rc = render_frame(s, p, scene_mem(s), build, true, d_rgb_f32, d_rgb_u8, d_hit_id, st, s->ev[slot][1]))) return rc;
-    if (rebuild) { s->grid_valid = true; s->build_clean = true; }
+    if (rebuild) { s->grid_valid = true; s->build_clean = true; s->grid_sorted = s->want_sorted(); }
     HIP_TRY(hipEventRecord(s->ev[slot][2], st));
     s->frames++;
     s->last_params = *p;
@@ -779,9 +839,9 @@ extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d
     m.grid = (RtGrid*)(base + L.grid); m.bounds_enc = (uint32_t*)(base + L.bounds_enc);
     m.cell_count = (uint32_t*)(base + L.cell_count); m.cell_start = (uint32_t*)(base + L.cell_start);
     m.block_sums = (uint32_t*)(base + L.block_sums); m.occupancy = (uint32_t*)(base + L.occupancy);
-    m.ref_tri = (uint32_t*)(base + L.ref_tri); m.ref_cell = (uint32_t*)(base + L.ref_cell); m.row_minmax = (uint2*)(base + L.row_minmax);
     m.recs = (float4*)(base + L.recs); m.blk_bounds = (float4*)(base + L.blk_bounds);
     m.ref_cap = RT_NOALLOC_MAX_REFS;
+    m.sorted = false;
     m.counters = (unsigned long long*)(base + L.counters);
     m.tile_list = (uint32_t*)(base + L.tile_list); m.tile_cost = (uint32_t*)(base + L.tile_cost); m.queue_lists = (uint32_t*)(base + L.queue_lists);
     m.tile_cap = RT_NOALLOC_MAX_TILES;
@@ -884,6 +944,13 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     out->primary_rays = rows * (uint64_t)p.width;
     out->hits = c[0];
     out->shadowed = c[1];
+    return RT_OK;
+}
+
+extern "C" int rt_scene_record_order(rt_scene* s, double area[2], int32_t* sorted) {
+    if (!s || !area || !sorted) return set_err(RT_ERR_INVALID, "rt_scene_record_order: bad argument");
+    area[0] = s->run_area[0]; area[1] = s->run_area[1];
+    *sorted = s->want_sorted() ? 1 : 0;
     return RT_OK;
 }
 

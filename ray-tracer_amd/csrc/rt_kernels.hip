@@ -376,6 +376,76 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
     }
 }
 
+// SCATTER + EMIT: the default second half of the build. As k_scatter, but what goes into the claimed slot is the
+// triangle's 48-byte test record itself, so the voxel lists are final after this kernel: no reference arrays, no sort, no
+// ranking. The records of a voxel end up in the order the atomics hand the slots out (consecutive triangles of a
+// wavefront stay together, in descending index); the render kernel's nearest-hit update does not depend on it.
+__global__ void __launch_bounds__(256) k_scatter_emit(RtBuildDev b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const RtGrid g = *b.grid;
+    if (g.n_refs > b.ref_cap) {              // cannot scatter: flag it and leave cell_count clear for the next build
+        if (i == 0) b.grid->overflow = 1;
+        for (uint32_t c = i; c < RT_MAX_CELLS; c += gridDim.x * blockDim.x) b.cell_count[c] = 0;
+        return;
+    }
+    const bool valid = i < b.n_tris;
+    int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
+    float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
+    if (valid) {
+        tri_voxel_range(b, g, i, vmin, vmax);
+        const float4* r = b.tri_rec + 3ull * i;
+        rec0 = r[0]; rec1 = r[1]; rec2 = r[2];
+    }
+    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
+    const int n = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
+    int x = 0, y = 0, z = 0;
+    for (int r = 0;; ++r) {
+        const bool act = r < n;
+        if (!__ballot(act)) break;
+        const int c = (vmin[2] + z) * nxy + (vmin[1] + y) * nx + (vmin[0] + x);
+        if (++x == ex) { x = 0; if (++y == ey) { y = 0; ++z; } }
+        uint32_t start = 0;
+        if (act) start = b.cell_start[c];
+        int leader; uint32_t rank, group;
+        lane_groups(act, c, lane, leader, rank, group);
+        uint32_t old = 0;
+        if (act && lane == leader) old = atomicSub(&b.cell_count[c], group);
+        old = (uint32_t)__shfl((int)old, leader);
+        if (act) {
+            float4* o = b.recs + 3ull * (start + old - 1u - rank);
+            o[0] = rec0; o[1] = rec1; o[2] = rec2;
+        }
+    }
+}
+
+// The same for small meshes, one wavefront per triangle like k_count_wide.
+__global__ void __launch_bounds__(256) k_scatter_emit_wide(RtBuildDev b) {
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const RtGrid g = *b.grid;
+    if (g.n_refs > b.ref_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) b.grid->overflow = 1;
+        for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < RT_MAX_CELLS; c += gridDim.x * blockDim.x) b.cell_count[c] = 0;
+        return;
+    }
+    if (i >= b.n_tris) return;
+    int vmin[3], vmax[3];
+    tri_voxel_range(b, g, i, vmin, vmax);
+    const float4* rr = b.tri_rec + 3ull * i;
+    const float4 rec0 = rr[0], rec1 = rr[1], rec2 = rr[2];
+    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1, exy = ex * ey;
+    const int n = exy * (vmax[2] - vmin[2] + 1);
+    for (int r = lane; r < n; r += 64) {
+        const int z = r / exy, q = r - z * exy, y = q / ex, x = q - y * ex;
+        const int c = (vmin[2] + z) * nxy + (vmin[1] + y) * nx + (vmin[0] + x);
+        float4* o = b.recs + 3ull * (b.cell_start[c] + atomicSub(&b.cell_count[c], 1u) - 1u);
+        o[0] = rec0; o[1] = rec1; o[2] = rec2;
+    }
+}
+
 // SCATTER for small meshes, one wavefront per triangle like k_count_wide.
 __global__ void __launch_bounds__(256) k_scatter_wide(RtBuildDev b) {
     const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -647,6 +717,32 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
     }
 }
 
+// Sum of the surface areas of the run boxes: the chance that a line crosses a convex body is proportional to its
+// surface area, so this sum says how many runs a ray has to test on average. The host compares it between the two orders
+// of the records inside a voxel, once per triangle list.
+__global__ void __launch_bounds__(256) k_run_area(RtBuildDev b, double* out) {
+    __shared__ double part[4];
+    const uint32_t n_refs = b.grid->n_refs;
+    const uint32_t n_blk = (n_refs > b.ref_cap) ? 0u : (n_refs + 63u) / 64u;
+    double a = 0.0;
+    for (uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x; blk < n_blk; blk += gridDim.x * blockDim.x) {
+        const float4 lo = b.blk_bounds[3ull * blk], hi = b.blk_bounds[3ull * blk + 1];
+        const double dx = (double)hi.x - lo.x, dy = (double)hi.y - lo.y, dz = (double)hi.z - lo.z;
+        const double v = dx * dy + dy * dz + dz * dx;
+        if (v == v && v < 1e300) a += v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+hipError_t rt_launch_run_area(RtBuildDev b, double* out, hipStream_t st) {
+    k_run_area<<<256, 256, 0, st>>>(b, out);
+    return hipGetLastError();
+}
+
 hipError_t rt_launch_build_phase1(RtBuildDev b, bool first, hipStream_t st) {
     if (first) k_build_init<<<256, 256, 0, st>>>(b);
     if (b.n_tris && b.n_tris <= RT_WIDE_MAX_TRIS) {
@@ -665,10 +761,17 @@ hipError_t rt_launch_build_phase1(RtBuildDev b, bool first, hipStream_t st) {
 
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st) {
     if (b.n_tris == 0) return hipSuccess;
-    if (b.n_tris <= RT_WIDE_MAX_TRIS) k_scatter_wide<<<(b.n_tris + 3) / 4, 256, 0, st>>>(b);
-    else k_scatter<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
-    k_row_sort<<<1024, 256, 0, st>>>(b);
-    k_order_emit<<<2048, 256, 0, st>>>(b);
+    if (!b.sorted) {
+        if (b.n_tris <= RT_WIDE_MAX_TRIS) k_scatter_emit_wide<<<(b.n_tris + 3) / 4, 256, 0, st>>>(b);
+        else k_scatter_emit<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
+    } else {
+        // voxel lists in ascending triangle index, the reference's order: for the read-back of the lists and for the
+        // counting build of the render kernel, whose shadow-ray test counts are those of that order
+        if (b.n_tris <= RT_WIDE_MAX_TRIS) k_scatter_wide<<<(b.n_tris + 3) / 4, 256, 0, st>>>(b);
+        else k_scatter<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
+        k_row_sort<<<1024, 256, 0, st>>>(b);
+        k_order_emit<<<2048, 256, 0, st>>>(b);
+    }
     k_block_bounds<<<1024, 256, 0, st>>>(b);
     return hipGetLastError();
 }

@@ -213,6 +213,30 @@ def test_both_trace_kernels_give_the_golden_image(rt, plane10, monkeypatch, own,
         s.close()
 
 
+def test_record_order_inside_a_voxel_does_not_matter(rt, O, plane10, monkeypatch):
+    """The default build scatters the triangle records straight into their voxels, in whatever order the atomics hand the
+    places out; RT_SORTED_BUILD=1 restores ascending triangle index, the reference's order (Serial/grid.h:118-150). Both
+    builds, and every rebuild of the default one, give the same ids and colours bit for bit: the nearest-hit update of
+    the render kernel is order-free. Duplicated triangles make sure ties between indices occur."""
+    import torch
+    tmp = rt.Scene(); tmp.load_mesh(BLUB); v9 = rt.subdivide(tmp.triangles(), 2).copy(); tmp.close()
+    v9[:, 0::3] += 1.5
+    v9 = np.concatenate([v9, v9[::7], v9[::5]])                   # exact duplicates, far apart in index
+    o = O.OracleScene(); o.add_obj(SPOT); o.add_triangles(v9, (30, 200, 90))
+    W, H = 480, 300
+    o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0))
+    for sorted_build in ("0", "1"):
+        monkeypatch.setenv("RT_SORTED_BUILD", sorted_build)
+        s = rt.Scene(); s.load_mesh(SPOT); s.add_triangles(v9, (30, 200, 90))
+        p = rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL)
+        rgb_d = torch.empty((H, W, 3), dtype=torch.float32, device="cuda"); ids_d = torch.empty((H, W), dtype=torch.int32, device="cuda")
+        for _ in range(6):                                        # the grid is rebuilt every frame
+            s.render_device(p, rebuild_grid=True, d_rgb=rgb_d.data_ptr(), d_ids=ids_d.data_ptr())
+            torch.cuda.synchronize()
+            check_image(rgb_d.cpu().numpy(), ids_d.cpu().numpy(), o_rgb, o_ids)
+        s.close()
+
+
 def test_scene_grows_between_frames(rt, plane10):
     """The build kernels leave their counters reset for the next build of the scene; a triangle list that grows after
     frames have been rendered starts from scratch and gives the frames of a scene that was loaded in one go."""

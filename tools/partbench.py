@@ -7,6 +7,7 @@ rt = importlib.import_module("ray-tracer_amd")
 w = sys.argv[1]
 scene, pkw, W, H, label = bench.build_workload(rt, w)
 scene.upload()
+print(w, 'record order (area unsorted, sorted, sort?):', scene.record_order(), flush=True)
 stream = torch.cuda.current_stream().cuda_stream
 for n in [int(x) for x in sys.argv[2:]]:
     for part in (0, n - 1):
