@@ -37,6 +37,10 @@ PEAK_HBM = 8.0e12
 # Algorithmic work per unit: triangle test = 9 FP32 + 57 FP64 flops + 3 FP64 divides as written in
 # Triangle::Intersect; voxel step = 5 FP32 (1 add + 4 compares); ray = 60 FP32 flops + 9 FP32 divides
 # (generation, slab test, DDA set-up) + 2 FP64 (sqrt, divide of normalize).
+# Traversal stress: the same scene seen from close by, so that most primary rays enter the grid and walk a deep, crowded part
+# of it (Serial camera: 13 % of the stand-in's rays enter, 4 % hit; this one: 77 % enter, 31 % hit). Not the headline frame.
+STRESS_CAMERA = dict(cam_pos=(1.0, 1.6, 1.0), cam_target=(0.0, 0.2, -0.45))
+
 FLOP_TEST_F32, FLOP_TEST_F64 = 9, 60
 FLOP_STEP_F32 = 5
 FLOP_RAY_F32, FLOP_RAY_F64 = 69, 2
@@ -85,15 +89,18 @@ def gather_parts(part, world, rank, out=None):
     return out
 
 
-def cpu_baseline(rt, scene, pkw, W, H, budget_s=12.0):
+def cpu_baseline(rt, scene, pkw, W, H, walk, budget_s=12.0):
     """The oracle (C restatement of Serial/, bit-verified against the compiled reference) on ONE host core, in
-    the reference's own full-walk mode, on a bounded sample of rows of the same frame."""
+    the reference's own full-walk mode, on a bounded sample of rows of the same frame. The same rows of the frame the
+    GPU path renders in the benchmarked walk mode are compared with them pixel by pixel (second return value)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     o = O.OracleScene()
     o.add_triangles(scene.triangles())
     grid_ms = o.build_grid()
     p = O.default_params(W, H, walk_mode=0, **pkw)
+    g_rgb, _, g_ids = scene.render(rt.default_params(W, H, walk_mode=walk, **pkw))
+    n_px = n_id = n_col = n_bits = 0
     rows_done, t_ms, rays = 0, 0.0, 0
     stride = max(1, H // 16)
     offsets = list(range(0, stride))
@@ -103,8 +110,13 @@ def cpu_baseline(rt, scene, pkw, W, H, budget_s=12.0):
     for off in offsets:
         for y in range(off, H, stride):
             before = cnt.hits
-            _, _, ms = o.render(p, y0=y, y1=y + 1, want_rgb=True, want_ids=False, counters=cnt)
+            o_rgb, o_ids, ms = o.render(p, y0=y, y1=y + 1, want_rgb=True, want_ids=True, counters=cnt)
             t_ms += ms
+            d = np.abs(g_rgb[y:y + 1].astype(np.float64) - o_rgb.astype(np.float64)).max(axis=-1)
+            n_px += W
+            n_id += int((g_ids[y:y + 1] != o_ids).sum())
+            n_col += int((np.where(np.isnan(d), np.inf, d) > 1.0).sum())
+            n_bits += int((g_rgb[y:y + 1].view(np.uint32) != o_rgb.view(np.uint32)).any(axis=-1).sum())
             rows_done += 1
             rays += W + (cnt.hits - before)
         if time.time() - t_start > budget_s:
@@ -112,7 +124,10 @@ def cpu_baseline(rt, scene, pkw, W, H, budget_s=12.0):
     frac = rows_done / H
     est_frame_ms = grid_ms + t_ms / frac
     est_rays = rays / frac
-    return {
+    parity = {"against": "oracle, full walk (what the reference executes)", "gpu_walk": "full" if walk == rt.RT_WALK_FULL else "early",
+              "pixels_checked": n_px, "rows_checked": rows_done, "id_mismatch": n_id, "colour_gt_1_255": n_col, "colour_bits_differ": n_bits,
+              "agreement": round(1.0 - n_col / max(n_px, 1), 7)}
+    return parity, {
         "value": round(est_rays / est_frame_ms / 1e3, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
         "sample": "%d of %d rows (every %dth row, %d passes) of the same frame, full-walk like the reference; "
                   "frame time extrapolated = grid build %.1f ms + rows %.1f ms / %.4f" % (rows_done, H, stride, rows_done * stride // H + 1, grid_ms, t_ms, frac),
@@ -224,6 +239,72 @@ def main():
     cs = scene.last_stats()
     scene.set_counting(False)
 
+    # Frame including the writeback to a host-visible buffer (Serial/raytracer.cpp:141,178-185 ends with the image in host
+    # memory): RGB8 into pinned host memory, copied on a stream of its own, so that frame k's copy runs beside frame k+1's
+    # grid build; two device and two host buffers. Single GPU only (on N GPUs rank 0 holds the gathered frame).
+    wb = None
+    if world == 1:
+        copy_stream = torch.cuda.Stream(device=dev)
+        main_stream = torch.cuda.current_stream()
+        d_buf = [part_u8, torch.empty_like(part_u8)]
+        h_buf = [torch.empty((rows, W, 3), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        ev_r = [torch.cuda.Event() for _ in range(2)]
+        ev_c = [torch.cuda.Event() for _ in range(2)]
+
+        def step_wb(k):
+            b = k & 1
+            if k >= 2:
+                main_stream.wait_event(ev_c[b])                 # the copy of frame k-2 has left this device buffer
+            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=d_buf[b].data_ptr(), stream=stream)
+            ev_r[b].record(main_stream)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ev_r[b])
+                h_buf[b].copy_(d_buf[b], non_blocking=True)
+                ev_c[b].record(copy_stream)
+
+        for k in range(max(args.warmup, 2)):
+            step_wb(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step_wb(k)
+        torch.cuda.synchronize()
+        dt_wb = (time.perf_counter() - t0) / args.steps
+        last = (args.steps - 1) & 1
+        wb = {"ms": round(dt_wb * 1e3, 4), "bytes_equal": bool(torch.equal(h_buf[last], d_buf[last].cpu())),
+              "mrays": round(rays_local / dt_wb / 1e6, 2), "bytes_per_frame": int(h_buf[0].numel())}
+
+    # Traversal stress beside the headline: same scene, close camera (untimed by the driver; a few frames)
+    stress = None
+    if world == 1 and args.workload in ("nefertiti4k", "nefertiti8k") and "cam_pos" not in pkw:
+        ps = rt.default_params(W, H, walk_mode=walk, **STRESS_CAMERA)
+        n_s = max(3, min(args.steps, 10))
+        for _ in range(2):
+            scene.render_device(ps, rebuild_grid=not args.no_rebuild, d_u8=part_u8.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_s):
+            scene.render_device(ps, rebuild_grid=not args.no_rebuild, d_u8=part_u8.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        dt_s = (time.perf_counter() - t0) / n_s
+        st_s = [scene.stats_at(i) for i in range(n_s)]
+        ms_r = float(np.mean([x["ms_render"] for x in st_s])); ms_b = float(np.mean([x["ms_build"] for x in st_s]))
+        scene.set_counting(True)
+        scene.render_device(ps, rebuild_grid=False, d_u8=part_u8.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        c2 = scene.last_stats()
+        scene.set_counting(False)
+        nr = c2["primary_rays"] + c2["hits"]
+        f32s = c2["tests_executed"] * FLOP_TEST_F32 + (c2["steps_primary"] + c2["steps_shadow"]) * FLOP_STEP_F32 + nr * FLOP_RAY_F32
+        f64s = c2["tests_executed"] * FLOP_TEST_F64 + nr * FLOP_RAY_F64
+        stress = {"workload": "same scene, camera %s -> %s (%.0f %% of the primary rays enter the grid, %.0f %% hit)" % (
+                      STRESS_CAMERA["cam_pos"], STRESS_CAMERA["cam_target"], 100.0 * c2["primary_entering"] / c2["primary_rays"], 100.0 * c2["hits"] / c2["primary_rays"]),
+                  "value": round(nr / dt_s / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(dt_s * 1e3, 4), "frames": n_s,
+                  "frame_ms": {"build": round(ms_b, 4), "render": round(ms_r, 4)},
+                  "ns_per_entering_ray": round(ms_r * 1e6 / max(c2["primary_entering"] + c2["shadow_entering"], 1), 3),
+                  "rays": int(nr), "entering": int(c2["primary_entering"] + c2["shadow_entering"]), "tests_executed": int(c2["tests_executed"]),
+                  "roofline_frac": round((f32s / PEAK_FP32 + f64s / PEAK_FP64) / (ms_r * 1e-3), 5)}
+
     tot = torch.tensor([rays_local, hits_local], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -264,7 +345,10 @@ def main():
                        "frame": "grid build + render + RGB8 framebuffer" + (" + RCCL gather + de-interleave" if world > 1 else ""),
                        "partition": "interleaved 8-row bands, scene replicated" if world > 1 else "single GPU",
                        "triangles": cs["n_triangles"], "grid": cs["grid_n"], "cell_refs": cs["n_refs"]},
-            "frame_ms": {"build": round(ms_build, 4), "render": round(ms_render, 4), "device_total": round(ms_build + ms_render, 4)},
+            "frame_ms": {"build": round(ms_build, 4), "render": round(ms_render, 4), "device_total": round(ms_build + ms_render, 4),
+                         "with_host_writeback": wb["ms"] if wb else None},
+            "host_writeback": wb,
+            "stress": stress,
             "render_only_mrays": round(rays_local / t_render / 1e6, 2) if t_render > 0 else None,
             "roofline": {
                 "bound": "valu", "kernel": "k_trace",
@@ -283,7 +367,7 @@ def main():
             },
         }
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(rt, scene, pkw, W, H)
+            out["parity"], out["cpu_baseline"] = cpu_baseline(rt, scene, pkw, W, H, walk)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
