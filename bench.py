@@ -181,18 +181,34 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     scene.upload()          # triangles resident in HBM before anything is timed
 
-    def step():
-        scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_u8.data_ptr(), stream=stream)
+    # N > 1: the exchange (gather to rank 0 + band de-interleave there) of frame k runs on a stream of its own beside the
+    # grid build and the trace of frame k + 1; two band buffers take turns. The frame rate is then that of the slower of
+    # the two pipelines instead of their sum.
+    main_stream = torch.cuda.current_stream()
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    part_bufs = [part_u8, torch.empty_like(part_u8)] if world > 1 else [part_u8]
+    ev_rendered = [torch.cuda.Event() for _ in part_bufs]
+    ev_exchanged = [torch.cuda.Event() for _ in part_bufs]
+
+    def step(k):
+        b = k % len(part_bufs)
+        if world > 1 and k >= len(part_bufs):
+            main_stream.wait_event(ev_exchanged[b])             # the gather of frame k - 2 has read this band buffer
+        scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[b].data_ptr(), stream=stream)
         if world > 1:
-            if rehearsal:
-                torch.cuda.synchronize()
-                g = gather_parts(part_u8.cpu(), world, rank)
+            ev_rendered[b].record(main_stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev_rendered[b])
+                if rehearsal:
+                    comm_stream.synchronize()
+                    g = gather_parts(part_bufs[b].cpu(), world, rank)
+                    if rank == 0:
+                        gathered.copy_(g)
+                else:
+                    gather_parts(part_bufs[b], world, rank, out=gathered)
                 if rank == 0:
-                    gathered.copy_(g)
-            else:
-                gather_parts(part_u8, world, rank, out=gathered)
-            if rank == 0:
-                rt.deinterleave_device(p, gathered.data_ptr(), frame_u8.data_ptr(), 3, stream=stream)
+                    rt.deinterleave_device(p, gathered.data_ptr(), frame_u8.data_ptr(), 3, stream=comm_stream.cuda_stream)
+                ev_exchanged[b].record(comm_stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -200,12 +216,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -342,7 +358,7 @@ def main():
             "dtype": "f32+f64",
             "data": "synthetic" if "STAND-IN" in label or "plane" in label else "reference meshes",
             "config": {"workload": label, "walk": args.walk, "rays_per_frame": int(rays_total), "hits": int(hits_total),
-                       "frame": "grid build + render + RGB8 framebuffer" + (" + RCCL gather + de-interleave" if world > 1 else ""),
+                       "frame": "grid build + render + RGB8 framebuffer" + (" + RCCL gather + de-interleave (on their own stream, beside the next frame's build)" if world > 1 else ""),
                        "partition": "interleaved 8-row bands, scene replicated" if world > 1 else "single GPU",
                        "triangles": cs["n_triangles"], "grid": cs["grid_n"], "cell_refs": cs["n_refs"]},
             "frame_ms": {"build": round(ms_build, 4), "render": round(ms_render, 4), "device_total": round(ms_build + ms_render, 4),

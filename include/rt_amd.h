@@ -142,6 +142,21 @@ int64_t rt_selftest_division(const double* num, const double* den, int64_t n);
  * each (rank-major), dst is the full row-major frame. elem_bytes = bytes per pixel (12, 3 or 4). */
 int rt_deinterleave_device(const rt_params* p, const void* d_src, void* d_dst, int32_t elem_bytes, void* stream);
 
+/* ---- multi-GPU exchange step (no counterpart in the reference, which runs on one thread): one process drives several
+ * GPUs, every GPU renders the bands of its part (rt_render_device with part_index = its place in `devices`, part_count =
+ * n_devices, on a scene uploaded to that GPU), and one RCCL gather brings the bands to the first GPU, each peer over its
+ * own xGMI link. RCCL is loaded at run time; without it rt_comm_create fails with RT_ERR_HIP. */
+typedef struct rt_comm rt_comm;
+/* One RCCL communicator per listed device (ncclCommInitAll); devices == NULL means 0 .. n_devices-1. */
+int rt_comm_create(int32_t n_devices, const int32_t* devices, rt_comm** out);
+void rt_comm_destroy(rt_comm* c);
+int32_t rt_comm_size(const rt_comm* c);
+/* d_parts[r]: the band buffer of part r on device r (rt_part_rows() rows of width * elem_bytes bytes); d_stacked
+ * (n_devices band buffers) and d_frame (the whole frame) live on the first device. The gather is enqueued on streams[r]
+ * of every device (NULL = their default streams) and rt_deinterleave_device() behind it on the first device's stream;
+ * the call does not wait for the GPUs. p->part_count must equal the communicator's size. */
+int rt_gather_bands(rt_comm* c, const rt_params* p, void* const* d_parts, void* d_stacked, void* d_frame, int32_t elem_bytes, void* const* streams);
+
 /* PPM writer of Serial/raytracer.cpp:178-185 from a float image. */
 int rt_write_ppm(const char* path, const float* rgb, int32_t w, int32_t h);
 /* Same from already quantised bytes. */

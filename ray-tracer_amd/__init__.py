@@ -72,7 +72,7 @@ EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
     "rt_render_device", "rt_render_device_noalloc", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_unit_costs",
-    "rt_deinterleave_device", "rt_selftest_division",
+    "rt_deinterleave_device", "rt_selftest_division", "rt_comm_create", "rt_comm_destroy", "rt_comm_size", "rt_gather_bands",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
 
@@ -124,6 +124,11 @@ def lib():
     L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
     L.rt_render_device_noalloc.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rt_deinterleave_device.argtypes = [vp, vp, vp, i32, vp]
+    L.rt_comm_create.argtypes = [i32, vp, C.POINTER(vp)]
+    L.rt_comm_destroy.argtypes = [vp]
+    L.rt_comm_size.argtypes = [vp]
+    L.rt_comm_size.restype = i32
+    L.rt_gather_bands.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     L.rt_selftest_division.argtypes = [vp, vp, i64]
     L.rt_selftest_division.restype = i64
     L.rt_write_ppm.argtypes = [C.c_char_p, vp, i32, i32]
@@ -294,6 +299,31 @@ def deinterleave_host(params, stacked):
 
 def deinterleave_device(params, d_src, d_dst, elem_bytes, stream=None):
     _check(lib().rt_deinterleave_device(C.byref(params), d_src, d_dst, elem_bytes, stream))
+
+
+class Comm:
+    """rt_comm: one process, several GPUs, RCCL gather of the rendered bands to the first of them."""
+
+    def __init__(self, devices):
+        devices = list(devices)
+        arr = (C.c_int32 * len(devices))(*devices)
+        self.h = C.c_void_p()
+        _check(lib().rt_comm_create(len(devices), arr, C.byref(self.h)))
+        self.devices = devices
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rt_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def gather_bands(self, params, d_parts, d_stacked, d_frame, elem_bytes, streams=None):
+        n = len(self.devices)
+        parts = (C.c_void_p * n)(*d_parts)
+        st = (C.c_void_p * n)(*streams) if streams is not None else None
+        _check(lib().rt_gather_bands(self.h, C.byref(params), parts, d_stacked, d_frame, elem_bytes, st))
 
 
 def selftest_division(num, den):

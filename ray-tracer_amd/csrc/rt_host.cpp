@@ -40,6 +40,15 @@ static int set_err(int code, const char* fmt, ...) {
     catch (const std::bad_alloc&) { return (T)set_err(RT_ERR_NOMEM, "out of host memory"); }            \
     catch (...) { return (T)set_err(RT_ERR_INVALID, "unexpected C++ exception"); }
 
+// for the other translation units of the library
+int rt_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 extern "C" const char* rt_last_error(void) { return g_err; }
 extern "C" const char* rt_version(void) { return "rt_amd 0.1 (gfx950)"; }
 
