@@ -72,6 +72,7 @@ struct RtOutputs {
     uint32_t* unit_info;          // counting build only: tile | unit shift << 24 | queue list << 28 of every work unit (may be NULL)
     uint32_t* tile_cycles;        // counting build only: shader cycles per tile of the frame, summed over its units (may be NULL)
     unsigned long long* counters; // [0] hits, [1] shadowed, [2..4] primary entered/steps/tests, [5..7] shadow entered/steps/tests
+    unsigned long long* stamps;   // when not NULL: [1] start and [2] end of the trace kernel on the 100 MHz real-time clock
 };
 
 // Per-frame work list of the render kernels.
@@ -89,6 +90,7 @@ struct RtRenderWork {
     int32_t bitmap_words;         // LDS words reserved for the occupancy bitmap (>= ceil(n_cells / 32))
     int32_t n_cu, blocks_per_cu;
     int32_t tx0, ntx, tb0, ntb;   // tile columns x local bands that may see the grid (conservative); the rest stays background
+    unsigned long long* stamp_start;   // when not NULL, k_classify writes the real-time clock here (frame start of a frame without a build)
 };
 
 // Build-time scratch.
@@ -111,6 +113,7 @@ struct RtBuildDev {
     float4* blk_bounds;           // 3 * (ref_cap / 64 + 2)
     uint32_t ref_cap;
     unsigned long long* counters;
+    unsigned long long* stamp;    // when not NULL, the first kernel of the build writes the 100 MHz real-time clock here (frame start)
     int32_t sorted;               // 1: voxel lists in ascending triangle index (scatter, row sort, ranking; needs ref_tri, ref_cell,
                                   // row_minmax); 0: records scattered straight into their voxels, in no particular order
 };

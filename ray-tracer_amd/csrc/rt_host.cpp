@@ -98,8 +98,10 @@ struct rt_scene {
     DevBuf<float> o_rgb;
     DevBuf<uint8_t> o_u8;
     DevBuf<int32_t> o_id;
-    hipEvent_t ev[RT_STATS_RING][3] = {};
+    DevBuf<unsigned long long> stamps;       // per ring slot: [0] frame start, [1] trace start, [2] trace end (100 MHz real-time clock,
+                                             // written by the kernels), [3] unused
     bool built[RT_STATS_RING] = {};
+    bool start_is_trace[RT_STATS_RING] = {};  // a frame without a build and without visible tiles starts with the trace kernel
     uint64_t frames = 0;               // frames rendered so far; frame k uses ring slot k % RT_STATS_RING
     bool count_work = false;
     // scheduling of the trace kernel: a tile is "expensive" when its estimate exceeds 1/thr0 of the even share of one
@@ -112,8 +114,7 @@ struct rt_scene {
     hipStream_t last_stream = nullptr;       // stream of the last frame or grid build (build state is shared between frames)
     bool stream_used = false;
     hipStream_t side_stream = nullptr;       // work-list preparation beside the grid build
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_start = nullptr;
-    hipEvent_t ev_done = nullptr;            // end of the last frame or grid build on last_stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     rt_params last_params;
     // experiment overrides, read once when the scene is created: RT_OWN_PATH (-1 = the library decides), RT_CULL_MIN
     // (1..65535), RT_CULL_LANE_RUNS (0..64), RT_BLOCKS_PER_CU (0 = no cap)
@@ -171,11 +172,9 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
         s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->row_minmax.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); s->queue_lists.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
-        for (auto& slot : s->ev) for (auto& e : slot) if (e) (void)hipEventDestroy(e);
+        s->stamps.release();
         if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
         if (s->ev_join) (void)hipEventDestroy(s->ev_join);
-        if (s->ev_done) (void)hipEventDestroy(s->ev_done);
-        if (s->ev_start) (void)hipEventDestroy(s->ev_start);
         if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
     }
     delete s;
@@ -372,11 +371,8 @@ static int scene_bind_device(rt_scene* s) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        for (auto& slot : s->ev) for (auto& ev : slot) HIP_TRY(hipEventCreate(&ev));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&s->ev_start, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
     }
     return RT_OK;
@@ -424,19 +420,20 @@ static RtBuildDev build_args(rt_scene* s, const FrameMem& m) {
     b.ref_tri = m.ref_tri; b.ref_cell = m.ref_cell; b.row_minmax = m.row_minmax; b.recs = m.recs; b.blk_bounds = m.blk_bounds;
     b.ref_cap = (uint32_t)m.ref_cap;
     b.counters = m.counters;
+    b.stamp = nullptr;
     b.sorted = m.sorted ? 1 : 0;
     return b;
 }
 
 // The scene's build state (counters the build kernels leave reset, the work list, the fork/join events) is shared between
-// frames, so consecutive frames and grid builds of one scene have to be ordered. On one stream they are; when the caller
-// switches streams the new stream first waits for the end of the work enqueued on the old one.
+// frames, so consecutive frames and grid builds of one scene have to be ordered. On one stream they are. When the caller
+// switches streams the host waits for the work enqueued on the old one (a rare case; an event per frame just to be able
+// to order streams on the device would cost every frame about 6 us of idle GPU).
 static int scene_enter_stream(rt_scene* s, hipStream_t st) {
-    if (s->stream_used && st != s->last_stream) HIP_TRY(hipStreamWaitEvent(st, s->ev_done, 0));
+    if (s->stream_used && st != s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
     return RT_OK;
 }
 static int scene_leave_stream(rt_scene* s, hipStream_t st) {
-    HIP_TRY(hipEventRecord(s->ev_done, st));
     s->last_stream = st;
     s->stream_used = true;
     return RT_OK;
@@ -458,7 +455,7 @@ static int scene_measure_grid(rt_scene* s) {
     return RT_OK;
 }
 
-static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStream_t st, hipEvent_t after_phase1);
+static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStream_t st, hipEvent_t after_phase1, unsigned long long* stamp);
 
 // Which order of the records inside a voxel: the default build leaves them in the order the scatter's atomics hand the
 // places out, which costs nothing; ascending triangle index costs a sort and a ranking pass per build. The order never
@@ -483,7 +480,7 @@ static int scene_choose_record_order(rt_scene* s) {
     for (int mode = 1; mode >= 0 && e == hipSuccess; --mode) {        // sorted first, so that the unsorted grid is the one left behind
         FrameMem m = scene_mem(s);
         m.sorted = mode == 1;
-        if (build_grid_async(s, m, true, nullptr, nullptr)) { d_area.release(); return RT_ERR_HIP; }
+        if (build_grid_async(s, m, true, nullptr, nullptr, nullptr)) { d_area.release(); return RT_ERR_HIP; }
         e = rt_launch_run_area(build_args(s, m), d_area.p + mode, nullptr);
     }
     if (e == hipSuccess) e = hipMemcpy(s->run_area, d_area.p, 2 * sizeof(double), hipMemcpyDeviceToHost);
@@ -509,6 +506,10 @@ extern "C" int rt_scene_upload(rt_scene* s) {
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
         (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(RT_COUNTER_WORDS)))
         return rc;
+    if (!s->stamps.p) {
+        if ((rc = s->stamps.ensure(RT_STATS_RING * 4))) return rc;
+        HIP_TRY(hipMemset(s->stamps.p, 0, RT_STATS_RING * 4 * sizeof(unsigned long long)));
+    }
     HIP_TRY(hipDeviceSynchronize());         // frames of the previous triangle list may still be reading these buffers
     HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
     HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
@@ -538,9 +539,11 @@ extern "C" int rt_scene_upload(rt_scene* s) {
 // Grid build on the working memory `m`. `first`: the build counters in `m` have not been left reset by a completed
 // build (k_build_init runs). `after_phase1`, when given, is recorded once cell_start and the occupancy bitmap are final
 // (the records are not yet).
-static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStream_t st, hipEvent_t after_phase1) {
+static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStream_t st, hipEvent_t after_phase1, unsigned long long* stamp) {
     if ((size_t)s->known_refs > m.ref_cap) return set_err(RT_ERR_INVALID, "grid build: %u references exceed the capacity %zu", s->known_refs, m.ref_cap);
-    HIP_TRY(rt_launch_build_phase1(build_args(s, m), first, st));
+    RtBuildDev b1 = build_args(s, m);
+    b1.stamp = stamp;
+    HIP_TRY(rt_launch_build_phase1(b1, first, st));
     if (after_phase1) HIP_TRY(hipEventRecord(after_phase1, st));
     HIP_TRY(rt_launch_build_phase2(build_args(s, m), st));
     return RT_OK;
@@ -560,7 +563,7 @@ static int scene_build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_
     if (rc) return rc;
     const bool first = !s->build_clean;
     s->build_clean = false;
-    if ((rc = build_grid_async(s, scene_mem(s), first, st, after_phase1))) return rc;
+    if ((rc = build_grid_async(s, scene_mem(s), first, st, after_phase1, nullptr))) return rc;
     s->grid_valid = true;
     s->build_clean = true;
     s->grid_sorted = s->want_sorted();
@@ -675,32 +678,25 @@ static size_t frame_tiles(const rt_params* p) {
 }
 
 // One frame on the working memory `m`: clears the outputs, builds the grid when asked to, prepares the work list and
-// traces. `fork`: the scene's side stream and events may be used (work-list preparation beside the second half of the
-// build); without it everything is enqueued on `st` in order and nothing but kernels and memsets is issued.
+// traces. `fork`: the scene's side stream and events may be used; without it everything is enqueued on `st` in order and
+// nothing but kernels and memsets is issued.
 // `build`: 0 = the grid in `m` is current, 1 = rebuild, the build state in `m` was left clean, 2 = rebuild from scratch.
+// `stamps` (may be NULL): four device words the kernels write the frame's times into, see rt_scene::stamps.
 static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int build, bool fork, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id,
-                        hipStream_t st, hipEvent_t ev_trace_start) {
+                        hipStream_t st, unsigned long long* stamps, bool* start_is_trace) {
     int rc;
-    // With a grid build in the frame, everything that only needs the grid's cell table (clearing the outputs, the tile list
-    // and its cost classes) runs on a side stream beside the second half of the build and joins before the trace kernel.
-    // The clearing needs nothing of the grid: the side stream does it beside the first half of the build (it starts where
-    // the frame starts on `st`, that is after the frame before).
-    // Small meshes only: their frame waits for the side stream, while the build of a large mesh is the longer branch and
-    // its bounds kernel runs at half speed beside a 25 MB memset.
-    const bool use_side = fork && build != 0;
-    const bool clear_early = use_side && s->n_tris() <= 65536;
+    // Large meshes with a grid build in the frame: everything that only needs the grid's cell table (clearing the outputs,
+    // the tile list and its cost classes, about 0.14 ms at 4K) runs on a side stream beside the second half of the build and
+    // joins before the trace kernel. The fork and the join cost about 6 us and 12 us of idle stream each, which is more
+    // than small meshes (up to 65,536 triangles: the whole preparation takes 45 us) would gain: they stay on one stream.
+    const bool use_side = fork && build != 0 && s->n_tris() > 65536;
     hipStream_t side = st;
-    if (use_side) {
-        side = s->side_stream;
-        if (clear_early) {
-            HIP_TRY(hipEventRecord(s->ev_start, st));
-            HIP_TRY(hipStreamWaitEvent(side, s->ev_start, 0));
-        } else {
-            if ((rc = build_grid_async(s, m, build == 2, st, s->ev_fork))) return rc;
+    if (build != 0) {
+        if ((rc = build_grid_async(s, m, build == 2, st, use_side ? s->ev_fork : nullptr, stamps))) return rc;
+        if (use_side) {
+            side = s->side_stream;
             HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
         }
-    } else if (build != 0) {
-        if ((rc = build_grid_async(s, m, build == 2, st, nullptr))) return rc;
     }
     const bool counting = s->count_work && m.unit_cost;
     HIP_TRY(hipMemsetAsync(m.counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), side));
@@ -711,10 +707,6 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
         if (d_rgb_f32) HIP_TRY(hipMemsetAsync(d_rgb_f32, 0, out_px * 3 * sizeof(float), side));
         if (d_rgb_u8) HIP_TRY(hipMemsetAsync(d_rgb_u8, 0, out_px * 3, side));
         if (d_hit_id) HIP_TRY(hipMemsetAsync(d_hit_id, 0xff, out_px * sizeof(int32_t), side));
-    }
-    if (clear_early) {
-        if ((rc = build_grid_async(s, m, build == 2, st, s->ev_fork))) return rc;
-        HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
     }
 
     RtSceneDev sd;
@@ -743,6 +735,7 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
     RtOutputs o;
     o.rgb_f32 = (float*)d_rgb_f32; o.rgb_u8 = (uint8_t*)d_rgb_u8; o.hit_id = (int32_t*)d_hit_id;
     o.counters = m.counters;
+    o.stamps = stamps;
     o.unit_cost = nullptr; o.tile_cycles = nullptr; o.unit_info = nullptr;
     const RtCamera cam = make_camera(p);
     RtRenderWork wk;
@@ -783,12 +776,15 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
         wk.blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
         if (s->blocks_per_cu_cap >= 1 && s->blocks_per_cu_cap < wk.blocks_per_cu) wk.blocks_per_cu = s->blocks_per_cu_cap;
     }
+    // without a build the first kernel of the frame is the tile classification, if any tile can see the grid at all
+    const bool prep_runs = wk.ntx * wk.ntb > 0 && sd.n_tris != 0;
+    wk.stamp_start = (build == 0 && prep_runs) ? stamps : nullptr;
+    if (start_is_trace) *start_is_trace = build == 0 && !prep_runs;
     HIP_TRY(rt_launch_render_prep(sd, cam, sh, f, wk, side));
     if (side != st) {
         HIP_TRY(hipEventRecord(s->ev_join, side));
         HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
     }
-    if (ev_trace_start) HIP_TRY(hipEventRecord(ev_trace_start, st));
     HIP_TRY(rt_launch_trace(sd, cam, sh, f, o, wk, st));
     return RT_OK;
 }
@@ -807,13 +803,11 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     if (s->count_work && (rc = s->unit_cost.ensure(tiles * 112))) return rc;
     if (rebuild && (rc = scene_ensure_refs(s))) return rc;
     const int slot = (int)(s->frames % RT_STATS_RING);
-    HIP_TRY(hipEventRecord(s->ev[slot][0], st));
     s->built[slot] = rebuild;
     int build = 0;
     if (rebuild) { build = s->build_clean ? 1 : 2; s->build_clean = false; }
-    if ((rc = render_frame(s, p, scene_mem(s), build, true, d_rgb_f32, d_rgb_u8, d_hit_id, st, s->ev[slot][1]))) return rc;
+    if ((rc = render_frame(s, p, scene_mem(s), build, true, d_rgb_f32, d_rgb_u8, d_hit_id, st, s->stamps.p + 4 * slot, &s->start_is_trace[slot]))) return rc;
     if (rebuild) { s->grid_valid = true; s->build_clean = true; s->grid_sorted = s->want_sorted(); }
-    HIP_TRY(hipEventRecord(s->ev[slot][2], st));
     s->frames++;
     s->last_params = *p;
     return scene_leave_stream(s, st);
@@ -856,7 +850,7 @@ extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d
     m.tile_cap = RT_NOALLOC_MAX_TILES;
     m.unit_cost = nullptr;
     // one stream, no events, no side stream: kernels and memsets only
-    return render_frame(s, p, m, 2, false, d_rgb_f32, d_rgb_u8, d_hit_id, (hipStream_t)stream, nullptr);
+    return render_frame(s, p, m, 2, false, d_rgb_f32, d_rgb_u8, d_hit_id, (hipStream_t)stream, nullptr, nullptr);
 }
 
 extern "C" int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id) {
@@ -926,12 +920,18 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     if (s->frames == 0) return set_err(RT_ERR_INVALID, "no frame rendered yet");
     if (frames_back < 0 || frames_back >= RT_STATS_RING || (uint64_t)frames_back >= s->frames) return set_err(RT_ERR_INVALID, "frame %d is not in the stats ring", frames_back);
     const int slot = (int)((s->frames - 1 - (uint64_t)frames_back) % RT_STATS_RING);
-    hipEvent_t* ev = s->ev[slot];
     memset(out, 0, sizeof(*out));
-    HIP_TRY(hipEventSynchronize(s->ev[(s->frames - 1) % RT_STATS_RING][2]));
-    HIP_TRY(hipEventElapsedTime(&out->ms_build, ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(&out->ms_render, ev[1], ev[2]));
-    HIP_TRY(hipEventElapsedTime(&out->ms_total, ev[0], ev[2]));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    {
+        // ticks of the 100 MHz real-time clock, written by the frame's kernels
+        unsigned long long t[4];
+        HIP_TRY(hipMemcpy(t, s->stamps.p + 4 * slot, sizeof(t), hipMemcpyDeviceToHost));
+        if (s->start_is_trace[slot]) t[0] = t[1];
+        const double ms_per_tick = 1e-5;
+        if (t[1] >= t[0]) out->ms_build = (float)((double)(t[1] - t[0]) * ms_per_tick);
+        if (t[2] >= t[1]) out->ms_render = (float)((double)(t[2] - t[1]) * ms_per_tick);
+        if (t[2] >= t[0]) out->ms_total = (float)((double)(t[2] - t[0]) * ms_per_tick);
+    }
     if (!s->built[slot]) out->ms_build = 0.f;
     RtGrid g;
     unsigned long long c[24];
@@ -967,7 +967,7 @@ extern "C" int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out) {
     if (!s || !out) return set_err(RT_ERR_INVALID, "rt_scene_last_counts: bad argument");
     if (s->frames == 0) return set_err(RT_ERR_INVALID, "no frame rendered yet");
     memset(out, 0, sizeof(*out));
-    HIP_TRY(hipEventSynchronize(s->ev[(s->frames - 1) % RT_STATS_RING][2]));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
     unsigned long long c[24];
     HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
     out->primary_entering = c[2]; out->steps_primary = c[3]; out->tests_primary = c[4];

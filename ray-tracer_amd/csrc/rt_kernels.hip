@@ -88,7 +88,14 @@ hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh,
 // grid build, Serial/grid.h:79-153, as count / prefix-scan / scatter
 // ------------------------------------------------------------------------------------------------
 
+// Frame timings come from the 100 MHz real-time clock, written by the first and the last kernel of a frame themselves:
+// an event on the stream costs about 6 us of idle GPU per record, several of them per frame.
+__device__ __forceinline__ void stamp_now(unsigned long long* stamp) {
+    if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();
+}
+
 __global__ void k_build_init(RtBuildDev b) {
+    stamp_now(b.stamp);
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t c = i; c < RT_MAX_CELLS; c += stride) b.cell_count[c] = 0;
@@ -110,6 +117,7 @@ __device__ __forceinline__ void grid_setup(const RtBuildDev& b);
 template <bool FUSED>
 __global__ void __launch_bounds__(256) k_bounds(RtBuildDev b) {
     __shared__ float red[4][6];
+    stamp_now(b.stamp);
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t stride = gridDim.x * blockDim.x;
     // four triangles per trip: twelve loads in flight per lane
@@ -190,6 +198,7 @@ __device__ __forceinline__ void grid_setup(const RtBuildDev& b) {
 
 // Scene without triangles: no k_bounds, the set-up alone.
 __global__ void k_grid_setup(RtBuildDev b) {
+    stamp_now(b.stamp);
     if (threadIdx.x == 0 && blockIdx.x == 0) grid_setup(b);
 }
 
@@ -744,13 +753,16 @@ hipError_t rt_launch_run_area(RtBuildDev b, double* out, hipStream_t st) {
 }
 
 hipError_t rt_launch_build_phase1(RtBuildDev b, bool first, hipStream_t st) {
-    if (first) k_build_init<<<256, 256, 0, st>>>(b);
+    // only the first kernel launched stamps the start of the build
+    RtBuildDev b0 = b;
+    b.stamp = nullptr;
+    if (first) { k_build_init<<<256, 256, 0, st>>>(b0); b0.stamp = nullptr; }
     if (b.n_tris && b.n_tris <= RT_WIDE_MAX_TRIS) {
         const uint32_t nb = (b.n_tris + 255) / 256;
-        k_bounds<true><<<nb < 256 ? nb : 256, 256, 0, st>>>(b);    // its last block sets the grid up
+        k_bounds<true><<<nb < 256 ? nb : 256, 256, 0, st>>>(b0);    // its last block sets the grid up
     } else {
-        if (b.n_tris) k_bounds<false><<<256, 256, 0, st>>>(b);
-        k_grid_setup<<<1, 64, 0, st>>>(b);
+        if (b.n_tris) { k_bounds<false><<<256, 256, 0, st>>>(b0); b0.stamp = nullptr; }
+        k_grid_setup<<<1, 64, 0, st>>>(b0);
     }
     if (b.n_tris && b.n_tris <= RT_WIDE_MAX_TRIS) k_count_wide<<<(b.n_tris + 3) / 4, 256, 0, st>>>(b);
     else if (b.n_tris) k_count<<<(b.n_tris + 255) / 256, 256, 0, st>>>(b);
@@ -900,8 +912,9 @@ __device__ __forceinline__ void write_pixel(const RtFrame& f, const RtOutputs& o
 // tiles per wavefront: 16 on large frames (fewer atomics), 4 on small ones (shorter chains per wavefront)
 template <int RT_CLS_TILES_PER_WAVE>
 __global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, RtFrame f, uint32_t* work, uint32_t* tile_list, int tx0,
-                                                  int ntx, int tb0, int ntb) {
+                                                  int ntx, int tb0, int ntb, unsigned long long* stamp) {
     __shared__ uint32_t wave_cnt[4];
+    stamp_now(stamp);
     __shared__ uint32_t block_base;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tiles_x = (f.width + RT_TILE - 1) / RT_TILE;
@@ -1831,8 +1844,12 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
     const RtTraceArgs* A = reinterpret_cast<const RtTraceArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
     uint32_t* const work = A->work;
 
+    if (A->o.stamps && blockIdx.x == 0 && threadIdx.x == 0) A->o.stamps[1] = __builtin_amdgcn_s_memrealtime();
     const uint32_t n_listed = work[0];
-    if (n_listed == 0) return;
+    if (n_listed == 0) {
+        if (A->o.stamps && blockIdx.x == 0 && threadIdx.x == 0) A->o.stamps[2] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
     {
         const RtSceneDev& s = A->s;
         // occupancy bitmap of the whole grid into LDS, once per block
@@ -1974,6 +1991,12 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
         }
         if (in_unit) write_pixel(f, o, x, y_local, cr, cg, cb, id);
     }
+    // end of the kernel = the latest exit of a wavefront (the clock only goes up, so the maximum also beats whatever an
+    // earlier frame left in the slot)
+    {
+        unsigned long long* const stamps_end = A->o.stamps;      // read again: not worth a register pair through the loop
+        if (stamps_end && lane == 0) atomicMax(&stamps_end[2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
     unsigned long long* const counters = A->o.counters;
     if (counters) {
         if (lane == 0) {
@@ -2023,8 +2046,8 @@ static int trace_blocks(const RtFrame& f, const RtRenderWork& wk) {
 hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtRenderWork wk, hipStream_t st) {
     const int n_cls = wk.ntx * wk.ntb;
     if (n_cls <= 0 || s.n_tris == 0) return hipSuccess;
-    if (n_cls > 16384) k_classify<16><<<(n_cls + 63) / 64, 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
-    else k_classify<4><<<(n_cls + 15) / 16, 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb);
+    if (n_cls > 16384) k_classify<16><<<(n_cls + 63) / 64, 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb, wk.stamp_start);
+    else k_classify<4><<<(n_cls + 15) / 16, 256, 0, st>>>(s, cam, f, wk.work, wk.tile_list, wk.tx0, wk.ntx, wk.tb0, wk.ntb, wk.stamp_start);
     const int nb = (n_cls + 255) / 256;
     const float4 est_w = make_float4(wk.est_w[0], wk.est_w[1], wk.est_w[2], wk.est_w[3]);
     const size_t est_lds = (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4;
@@ -2098,7 +2121,11 @@ __global__ void k_deinterleave(const uint8_t* __restrict__ src, uint8_t* __restr
     const int band = y / RT_TILE, part = band % part_count, local_band = band / part_count;
     const uint8_t* srow = src + ((size_t)part * part_rows + (size_t)local_band * RT_TILE + (y % RT_TILE)) * row_bytes;
     uint8_t* drow = dst + (size_t)y * row_bytes;
-    if ((row_bytes & 3) == 0) {
+    if ((row_bytes & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const uint4* s16 = (const uint4*)srow;
+        uint4* d16 = (uint4*)drow;
+        for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes / 16; i += (size_t)gridDim.x * blockDim.x) d16[i] = s16[i];
+    } else if ((row_bytes & 3) == 0) {
         const uint32_t* s4 = (const uint32_t*)srow;
         uint32_t* d4 = (uint32_t*)drow;
         for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < row_bytes / 4; i += (size_t)gridDim.x * blockDim.x) d4[i] = s4[i];
@@ -2110,7 +2137,9 @@ __global__ void k_deinterleave(const uint8_t* __restrict__ src, uint8_t* __restr
 hipError_t rt_launch_deinterleave(const void* src, void* dst, int32_t width, int32_t height, int32_t part_count, int32_t part_rows,
                                   int32_t elem_bytes, hipStream_t st) {
     if (width <= 0 || height <= 0) return hipSuccess;
-    dim3 grid(8, height);
+    const size_t row_bytes = (size_t)width * elem_bytes;
+    const unsigned bx = (unsigned)((row_bytes / 16 + 255) / 256);
+    dim3 grid(bx < 1 ? 1 : (bx > 8 ? 8 : bx), height);
     k_deinterleave<<<grid, 256, 0, st>>>((const uint8_t*)src, (uint8_t*)dst, width, height, part_count, part_rows, elem_bytes);
     return hipGetLastError();
 }
