@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--walk", default="early", choices=["early", "full"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-rebuild", action="store_true", help="reuse the grid (render-only frames)")
+    ap.add_argument("--no-extras", action="store_true", help="headline frames only: no host-writeback loop, no stress camera (profiling runs: every "
+                                                                "launch of the trace kernel is then one of the timed frame's)")
     args = ap.parse_args()
 
     import torch
@@ -259,7 +261,7 @@ def main():
     # memory): RGB8 into pinned host memory, copied on a stream of its own, so that frame k's copy runs beside frame k+1's
     # grid build; two device and two host buffers. Single GPU only (on N GPUs rank 0 holds the gathered frame).
     wb = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         copy_stream = torch.cuda.Stream(device=dev)
         n_buf = int(os.environ.get("RT_WB_BUFFERS", "3"))
         # small frames: a copy kernel that writes the mapped host buffer; large ones: hipMemcpyAsync (measured on the test
@@ -301,7 +303,7 @@ def main():
 
     # Traversal stress beside the headline: same scene, close camera (untimed by the driver; a few frames)
     stress = None
-    if world == 1 and args.workload in ("nefertiti4k", "nefertiti8k") and "cam_pos" not in pkw:
+    if world == 1 and not args.no_extras and args.workload in ("nefertiti4k", "nefertiti8k") and "cam_pos" not in pkw:
         ps = rt.default_params(W, H, walk_mode=walk, **STRESS_CAMERA)
         n_s = max(3, min(args.steps, 10))
         for _ in range(2):
