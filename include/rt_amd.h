@@ -61,7 +61,8 @@ typedef struct rt_params {
 #define RT_BAND_ROWS 8
 #define RT_STATS_RING 128
 
-/* Device-side timings (hipEvents on the render stream) and the ray counts of the last frame. */
+/* Device-side timings (the frame's kernels write the GPU's 100 MHz real-time clock at their start and end) and the ray
+ * counts of the last frame. */
 typedef struct rt_frame_stats {
     float ms_build;                   /* grid build: bounds, count, scan, scatter, sort/record emit */
     float ms_render;                  /* render kernel incl. framebuffer writes */
@@ -126,7 +127,7 @@ int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d_rgb_f32, v
 int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id);
 /* render() including its file output: writes "P6\nW H\n255\n" + body to `path` ("./test.ppm" in the reference). */
 int rt_render_ppm(rt_scene* s, const rt_params* p, const char* path);
-/* Stats of the last rt_render_device()/rt_render() on this scene; synchronises on its events. Work counters and
+/* Stats of the last rt_render_device()/rt_render() on this scene; waits for the scene's stream. Work counters and
  * scheduling diagnostics of the counting build of the kernels are declared in rt_amd_diag.h. */
 int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out);
 /* Timings of the frame rendered `frames_back` frames before the last one (0 = last; a ring of RT_STATS_RING
