@@ -30,6 +30,11 @@ typedef enum rt_status {
 } rt_status;
 
 enum { RT_WALK_EARLY = 0, RT_WALK_FULL = 1 };
+/* Which fast_trace: the Serial tree's (Serial/raytracer.cpp:71-118; the parity target, pinned against the compiled
+ * reference) or the Parallel tree's (Parallel/raytracer.cu:445-524: per-mesh material table, nearest hit with t > eps,
+ * shadow ray towards the light, mirror reflection to depth 3). The Parallel tree is CUDA and cannot be compiled where this
+ * library is tested, so the second mode is checked against a CPU restatement only. */
+enum { RT_SHADE_SERIAL = 0, RT_SHADE_PARALLEL = 1 };
 
 /* Opaque scene: the triangle list that load_mesh() appends to, plus its device copy and grid. */
 typedef struct rt_scene rt_scene;
@@ -56,7 +61,21 @@ typedef struct rt_params {
      * stacked (local band j = global band part_index + j*part_count) into the output buffers, which
      * hold rt_part_rows() rows. part_count = 1 renders the whole frame. */
     int32_t part_index, part_count;
+    /* RT_SHADE_PARALLEL only (ignored otherwise). With it, kd / ks / ka / spec_alpha / light_intensity above are unused (the
+     * materials carry them), shadow_scale is the factor of a shadowed colour (0.5 at Parallel/raytracer.cu:505) and eps the
+     * hit threshold (1e-4 at Parallel/geometry.cuh:3). rt_params_default() leaves the Serial values in those two. */
+    int32_t shading_mode;             /* RT_SHADE_SERIAL */
+    int32_t reflect_depth;            /* 3: REFLECT_DEPTH, Parallel/raytracer.cu:16 (at most 3) */
+    float shadow_bias;                /* 0.02f: the shadow ray starts at eps + 0.02f, Parallel/raytracer.cu:494 */
 } rt_params;
+
+/* One entry of the material table of the Parallel tree's fast_trace (Parallel/geometry.cuh:284-303, raytracer.cu:450-453);
+ * here a material travels with the mesh it is loaded for instead of being compiled into the shader. */
+typedef struct rt_material {
+    float base_color[3];
+    float kd, ks, spec_alpha, ka, km;
+    int32_t reflective;
+} rt_material;
 
 #define RT_BAND_ROWS 8
 #define RT_STATS_RING 128
@@ -88,6 +107,12 @@ void rt_scene_destroy(rt_scene* s);
  * (coordinate + offset), 1-based face indices, triangle index = order of the f lines over all calls.
  * A missing file adds nothing and returns 0 like the reference. Returns triangles added or <0. */
 int64_t rt_scene_add_obj(rt_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]);
+/* load_mesh of the Parallel tree (Parallel/raytracer.cu:805-873): vertex = scale * (coordinate + offset), evaluated in double
+ * and rounded to float, and a material instead of a colour. With scale 1 the vertices are those of rt_scene_add_obj.
+ * Meshes added without a material get the table's entry 1 (kd 10, ks 10, spec_alpha 1.25, ka 0.3, not reflective) around
+ * their colour. */
+int64_t rt_scene_add_obj_material(rt_scene* s, const char* path, int format_has_vt, const rt_material* material, const float offset[3], int32_t scale);
+int64_t rt_scene_add_triangles_material(rt_scene* s, const float* v9, int64_t n, const rt_material* material);
 /* Same, for a mesh already in memory: n triangles, 9 floats each (v0 v1 v2). */
 int64_t rt_scene_add_triangles(rt_scene* s, const float* v9, int64_t n, const float color[3]);
 int64_t rt_scene_num_triangles(const rt_scene* s);

@@ -18,7 +18,16 @@ class Params(C.Structure):
         ("kd", C.c_float), ("ks", C.c_float), ("ka", C.c_float), ("spec_alpha", C.c_float),
         ("light_intensity", C.c_float), ("shadow_scale", C.c_float), ("eps", C.c_float),
         ("walk_mode", C.c_int32), ("early_slack", C.c_float),
+        ("reflect_depth", C.c_int32), ("shadow_bias", C.c_float),
     ]
+
+
+class Material(C.Structure):
+    _fields_ = [("base_color", C.c_float * 3), ("kd", C.c_float), ("ks", C.c_float), ("spec_alpha", C.c_float), ("ka", C.c_float),
+                ("km", C.c_float), ("reflective", C.c_int32)]
+
+    def __init__(self, base_color=(255, 0, 0), kd=10.0, ks=10.0, spec_alpha=1.25, ka=0.3, km=0.0, reflective=False):
+        super().__init__((C.c_float * 3)(*[float(x) for x in base_color]), kd, ks, spec_alpha, ka, km, int(bool(reflective)))
 
 
 class Counters(C.Structure):
@@ -47,6 +56,12 @@ def lib():
         L.rto_scene_add_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]
         L.rto_scene_add_triangles.restype = C.c_int64
         L.rto_scene_add_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.rto_scene_add_obj_material.restype = C.c_int64
+        L.rto_scene_add_obj_material.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.rto_scene_add_triangles_material.restype = C.c_int64
+        L.rto_scene_add_triangles_material.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.rto_render_rows_parallel.restype = C.c_double
+        L.rto_render_rows_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.rto_scene_num_triangles.restype = C.c_int64
         L.rto_scene_num_triangles.argtypes = [C.c_void_p]
         L.rto_scene_triangles.restype = C.POINTER(C.c_float)
@@ -98,6 +113,24 @@ class OracleScene:
     def add_triangles(self, v9, color=(255, 0, 0)):
         v9 = np.ascontiguousarray(v9, dtype=np.float32).reshape(-1, 9)
         return lib().rto_scene_add_triangles(self.h, v9.ctypes.data, v9.shape[0], _f3(color))
+
+    def add_obj_material(self, path, has_vt, material, offset=(0, 0, 0), scale=1):
+        return lib().rto_scene_add_obj_material(self.h, os.fsencode(path), int(has_vt), C.byref(material), _f3(offset), int(scale))
+
+    def add_triangles_material(self, v9, material):
+        v9 = np.ascontiguousarray(v9, dtype=np.float32).reshape(-1, 9)
+        return lib().rto_scene_add_triangles_material(self.h, v9.ctypes.data, v9.shape[0], C.byref(material))
+
+    def render_parallel(self, params, y0=0, y1=None):
+        """fast_trace of the Parallel tree (parity unpinned): returns (rgb float32 [rows,W,3], ids int32 [rows,W], ms)."""
+        if self.grid_ms is None:
+            self.build_grid()
+        y1 = params.height if y1 is None else y1
+        rows, w = y1 - y0, params.width
+        rgb = np.empty((rows, w, 3), np.float32)
+        ids = np.empty((rows, w), np.int32)
+        ms = lib().rto_render_rows_parallel(self.h, C.byref(params), y0, y1, rgb.ctypes.data, ids.ctypes.data)
+        return rgb, ids, ms
 
     @property
     def num_triangles(self):

@@ -17,6 +17,7 @@ struct rto_scene {
     int64_t ntri, cap;
     float* v;        /* 9 per triangle: v0 v1 v2 */
     float* color;    /* 3 per triangle (Triangle::material, Serial/geometry.h:113) */
+    float* mat;      /* 6 per triangle: kd, ks, spec_alpha, ka, km, reflective (material table of the Parallel tree) */
     /* grid */
     int built;
     int32_t n[3];
@@ -45,13 +46,15 @@ void rto_params_default(rto_params* p) {
     p->eps = 1e-1f;                                        /* Serial/geometry.h:2 */
     p->walk_mode = 0;
     p->early_slack = 0.f;
+    p->reflect_depth = 3;
+    p->shadow_bias = 0.02f;
 }
 
 rto_scene* rto_scene_create(void) { return (rto_scene*)calloc(1, sizeof(rto_scene)); }
 
 void rto_scene_destroy(rto_scene* s) {
     if (!s) return;
-    free(s->v); free(s->color); free(s->cell_start); free(s->cell_tris); free(s);
+    free(s->v); free(s->color); free(s->mat); free(s->cell_start); free(s->cell_tris); free(s);
 }
 
 static void scene_reserve(rto_scene* s, int64_t extra) {
@@ -60,16 +63,35 @@ static void scene_reserve(rto_scene* s, int64_t extra) {
     while (nc < s->ntri + extra) nc *= 2;
     s->v = (float*)realloc(s->v, (size_t)nc * 9 * sizeof(float));
     s->color = (float*)realloc(s->color, (size_t)nc * 3 * sizeof(float));
+    s->mat = (float*)realloc(s->mat, (size_t)nc * 6 * sizeof(float));
     s->cap = nc;
 }
 
-int64_t rto_scene_add_triangles(rto_scene* s, const float* v9, int64_t n, const float color[3]) {
+/* entry 1 of the Parallel tree's table (Parallel/raytracer.cu:451) around a colour */
+static rto_material default_material(const float color[3]) {
+    rto_material m;
+    memcpy(m.base_color, color, 3 * sizeof(float));
+    m.kd = 10.0f; m.ks = 10.0f; m.spec_alpha = 1.25f; m.ka = 0.3f; m.km = 0.f; m.reflective = 0;
+    return m;
+}
+static void set_material(rto_scene* s, int64_t i, const rto_material* m) {
+    memcpy(s->color + 3 * i, m->base_color, 3 * sizeof(float));
+    float* q = s->mat + 6 * i;
+    q[0] = m->kd; q[1] = m->ks; q[2] = m->spec_alpha; q[3] = m->ka; q[4] = m->km; q[5] = m->reflective ? 1.f : 0.f;
+}
+
+int64_t rto_scene_add_triangles_material(rto_scene* s, const float* v9, int64_t n, const rto_material* m) {
     scene_reserve(s, n);
     memcpy(s->v + 9 * s->ntri, v9, (size_t)n * 9 * sizeof(float));
-    for (int64_t i = 0; i < n; ++i) memcpy(s->color + 3 * (s->ntri + i), color, 3 * sizeof(float));
+    for (int64_t i = 0; i < n; ++i) set_material(s, s->ntri + i, m);
     s->ntri += n;
     s->built = 0;
     return n;
+}
+
+int64_t rto_scene_add_triangles(rto_scene* s, const float* v9, int64_t n, const float color[3]) {
+    rto_material m = default_material(color);
+    return rto_scene_add_triangles_material(s, v9, n, &m);
 }
 
 int64_t rto_scene_num_triangles(const rto_scene* s) { return s->ntri; }
@@ -105,6 +127,12 @@ static int read_int(const char** pp, const char* e) {
 }
 
 int64_t rto_scene_add_obj(rto_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]) {
+    rto_material m = default_material(color);
+    return rto_scene_add_obj_material(s, path, format_has_vt, &m, offset, 1);
+}
+
+int64_t rto_scene_add_obj_material(rto_scene* s, const char* path, int format_has_vt, const rto_material* mat, const float offset[3], int scale_i) {
+    const double scale = (double)scale_i;   /* Parallel/raytracer.cu:824: int * double; 1 for the Serial loader, where the product is exact */
     FILE* f = fopen(path, "rb");
     if (!f) return 0;                    /* a missing file gives an empty mesh, no error */
     fseek(f, 0, SEEK_END);
@@ -134,9 +162,9 @@ int64_t rto_scene_add_obj(rto_scene* s, const char* path, int format_has_vt, con
             double a = read_double(&q, le, &ok), b = read_double(&q, le, &ok), c = read_double(&q, le, &ok);
             if (nv == vcap) { vcap *= 2; verts = (float*)realloc(verts, (size_t)vcap * 3 * sizeof(float)); }
             /* double + (double)float, then rounded to float by the Vec3f constructor (:239) */
-            verts[3 * nv + 0] = (float)(a + (double)offset[0]);
-            verts[3 * nv + 1] = (float)(b + (double)offset[1]);
-            verts[3 * nv + 2] = (float)(c + (double)offset[2]);
+            verts[3 * nv + 0] = (float)(scale * (a + (double)offset[0]));
+            verts[3 * nv + 1] = (float)(scale * (b + (double)offset[1]));
+            verts[3 * nv + 2] = (float)(scale * (c + (double)offset[2]));
             ++nv;
         } else if (tl == 1 && p[0] == 'f') {
             int idx[3];
@@ -154,7 +182,7 @@ int64_t rto_scene_add_obj(rto_scene* s, const char* path, int format_has_vt, con
             scene_reserve(s, 1);
             float* o = s->v + 9 * s->ntri;
             for (int k = 0; k < 3; ++k) memcpy(o + 3 * k, verts + 3 * (int64_t)(idx[k] - 1), 3 * sizeof(float));
-            memcpy(s->color + 3 * s->ntri, color, 3 * sizeof(float));
+            set_material(s, s->ntri, mat);
             ++s->ntri; ++added;
         }
         /* "vt" records are parsed by the reference but unused; everything else is skipped */
@@ -479,6 +507,146 @@ double rto_render_rows(const rto_scene* s, const rto_params* p, int y0, int y1, 
         cn->steps_shadow += local.steps_shadow; cn->tests_shadow += local.tests_shadow;
     }
     return ms;
+}
+
+/* ---- the Parallel tree's fast_trace (PARITY UNPINNED, see rt_oracle.h) ---- */
+
+typedef struct {
+    double t;      /* t_min / tnear, a double that is never rounded (Parallel/raytracer.cu:459) */
+    int32_t id;    /* triangle_near */
+} near_par;
+
+/* Triangle::Intersect, Parallel/geometry.cuh:123-170: true only when eps < t < t_min (and then t_min = t). */
+static inline int tri_test_par(const float* tv, const float o[3], const float d[3], float eps, int32_t id, near_par* st) {
+    float e1x = tv[0] - tv[3], e1y = tv[1] - tv[4], e1z = tv[2] - tv[5];
+    float e2x = tv[0] - tv[6], e2y = tv[1] - tv[7], e2z = tv[2] - tv[8];
+    float sx = tv[0] - o[0], sy = tv[1] - o[1], sz = tv[2] - o[2];
+    double A = det3(e1x, e2x, d[0], e1y, e2y, d[1], e1z, e2z, d[2]);
+    double beta = det3(sx, e2x, d[0], sy, e2y, d[1], sz, e2z, d[2]) / A;
+    double gamma = det3(e1x, sx, d[0], e1y, sy, d[1], e1z, sz, d[2]) / A;
+    if (beta > 0 && gamma > 0 && beta + gamma < 1) {
+        double t = det3(e1x, e2x, sx, e1y, e2y, sy, e1z, e2z, sz) / A;
+        if (t < st->t && t > eps) { st->t = t; st->id = id; return 1; }
+    }
+    return 0;
+}
+
+/* GridAccel::Intersect, Parallel/grid.cuh:224-290 (the same walk as the Serial tree's). mode: WALK_FULL as the reference,
+ * WALK_NEAREST_EARLY stops once the nearest hit lies before the next crossing, WALK_ANY_EARLY at the first hit. */
+static int grid_walk_par(const rto_scene* s, const float o[3], const float d[3], float mint, float eps, int mode, near_par* st) {
+    float rayT;
+    float p0[3] = {o[0] + d[0] * mint, o[1] + d[1] * mint, o[2] + d[2] * mint};
+    int inside = p0[0] >= s->lo[0] && p0[0] <= s->hi[0] && p0[1] >= s->lo[1] && p0[1] <= s->hi[1] &&
+                 p0[2] >= s->lo[2] && p0[2] <= s->hi[2];
+    if (inside) rayT = mint;
+    else if (!slab_test(s, o, d, mint, &rayT)) return 0;
+    float gi[3] = {o[0] + d[0] * rayT, o[1] + d[1] * rayT, o[2] + d[2] * rayT};
+    float next[3], delta[3];
+    int step[3], out[3], pos[3];
+    for (int a = 0; a < 3; ++a) {
+        pos[a] = pos_to_voxel(s, gi[a], a);
+        if (d[a] >= 0) {
+            next[a] = rayT + (voxel_to_pos(s, pos[a] + 1, a) - gi[a]) / d[a];
+            delta[a] = s->width[a] / d[a];
+            step[a] = 1; out[a] = s->n[a];
+        } else {
+            next[a] = rayT + (voxel_to_pos(s, pos[a], a) - gi[a]) / d[a];
+            delta[a] = -s->width[a] / d[a];
+            step[a] = -1; out[a] = -1;
+        }
+    }
+    static const int cmp_to_axis[8] = {2, 1, 2, 1, 2, 2, 0, 0};
+    int hit = 0;
+    for (;;) {
+        int64_t c = (int64_t)pos[2] * s->n[0] * s->n[1] + (int64_t)pos[1] * s->n[0] + pos[0];
+        uint32_t b = s->cell_start[c], e = s->cell_start[c + 1];
+        for (uint32_t k = b; k < e; ++k) {
+            uint32_t id = s->cell_tris[k];
+            if (tri_test_par(s->v + 9 * (size_t)id, o, d, eps, (int32_t)id, st)) {
+                hit = 1;
+                if (mode == WALK_ANY_EARLY) return 1;
+            }
+        }
+        int bits = ((next[0] < next[1]) << 2) + ((next[0] < next[2]) << 1) + (next[1] < next[2]);
+        int ax = cmp_to_axis[bits];
+        if (mode == WALK_NEAREST_EARLY && hit && st->t < (double)next[ax]) break;
+        pos[ax] += step[ax];
+        if (pos[ax] == out[ax]) break;
+        next[ax] += delta[ax];
+    }
+    return hit;
+}
+
+/* fast_trace, Parallel/raytracer.cu:445-524, recursive like the reference. */
+static void fast_trace_par(const rto_scene* s, const rto_params* p, const float orig[3], const float dir_in[3], float mint, int depth,
+                           float out[3], int32_t* first_id) {
+    out[0] = out[1] = out[2] = 0.f;
+    near_par st = {INFINITY, -1};
+    const int pmode = p->walk_mode ? WALK_NEAREST_EARLY : WALK_FULL;
+    const int smode = p->walk_mode ? WALK_ANY_EARLY : WALK_FULL;
+    int hit = s->ntri > 0 ? grid_walk_par(s, orig, dir_in, mint, p->eps, pmode, &st) : 0;
+    if (first_id) *first_id = hit ? st.id : -1;
+    if (!hit) return;
+    const float* tv = s->v + 9 * (size_t)st.id;
+    const float* base = s->color + 3 * (size_t)st.id;
+    const float* m = s->mat + 6 * (size_t)st.id;
+    const float kd = m[0], ks = m[1], alpha = m[2], ka = m[3], km = m[4];
+    const int reflective = m[5] != 0.f;
+    const float tn = (float)st.t;                          /* Vec3f::scale takes a float */
+    float poi[3], v[3], l[3], h[3], n[3], color[3];
+    for (int a = 0; a < 3; ++a) poi[a] = orig[a] + dir_in[a] * tn;
+    for (int a = 0; a < 3; ++a) v[a] = -dir_in[a];
+    normalize3(v);
+    for (int a = 0; a < 3; ++a) l[a] = p->light_pos[a] - poi[a];
+    normalize3(l);
+    for (int a = 0; a < 3; ++a) h[a] = v[a] + l[a];
+    normalize3(h);
+    float a21[3] = {tv[6] - tv[3], tv[7] - tv[4], tv[8] - tv[5]};    /* v2 - v1 */
+    float a01[3] = {tv[0] - tv[3], tv[1] - tv[4], tv[2] - tv[5]};    /* v0 - v1 */
+    cross3(a21, a01, n);                                              /* Parallel/geometry.cuh:160 */
+    float fd = maxf_std(0.f, dot3(n, l));
+    float fs = powf(maxf_std(0.f, dot3(n, h)), alpha);
+    for (int a = 0; a < 3; ++a) color[a] = ((base[a] * fd) * kd + (base[a] * fs) * ks) + base[a] * ka;
+    /* shadow ray towards the light, :492-506 */
+    near_par sst = {INFINITY, -1};
+    if (grid_walk_par(s, poi, l, p->eps + p->shadow_bias, p->eps, smode, &sst))
+        for (int a = 0; a < 3; ++a) color[a] = color[a] * p->shadow_scale;
+    if (reflective && depth < p->reflect_depth) {
+        float I[3] = {dir_in[0], dir_in[1], dir_in[2]}, r[3], rec[3];
+        normalize3(I);
+        normalize3(n);
+        float factor = dot3(I, n) * 2;
+        for (int a = 0; a < 3; ++a) r[a] = I[a] - n[a] * factor;
+        normalize3(r);
+        fast_trace_par(s, p, poi, r, p->eps, depth + 1, rec, NULL);
+        for (int a = 0; a < 3; ++a) out[a] = (color[a] * base[a]) * (1 - km) + rec[a] * km;
+        return;
+    }
+    for (int a = 0; a < 3; ++a) out[a] = color[a];
+}
+
+double rto_render_rows_parallel(const rto_scene* s, const rto_params* p, int y0, int y1, float* rgb, int32_t* ids) {
+    camera_t cam;
+    camera_setup(p, &cam);
+    const int W = p->width, H = p->height;
+    double t0 = now_ms();
+    for (int y = y0; y < y1; ++y) {
+        for (int x = 0; x < W; ++x) {
+            size_t o = (size_t)(y - y0) * W + x;
+            float dir[3], c3[3];
+            for (int a = 0; a < 3; ++a) dir[a] = 0.f + (-cam.w[a]) * cam.focal_distance;     /* Parallel/raytracer.cu:352-359 */
+            float xw = (float)((double)cam.aspect * (x - W / 2.0 + 0.5) / W);
+            float yw = (float)((y - H / 2.0 + 0.5) / H);
+            for (int a = 0; a < 3; ++a) dir[a] = dir[a] + cam.u[a] * xw;
+            for (int a = 0; a < 3; ++a) dir[a] = dir[a] + cam.v[a] * yw;
+            normalize3(dir);
+            int32_t id = -1;
+            fast_trace_par(s, p, cam.pos, dir, 0.f, 0, c3, &id);
+            if (ids) ids[o] = id;
+            if (rgb) { rgb[3 * o] = c3[0]; rgb[3 * o + 1] = c3[1]; rgb[3 * o + 2] = c3[2]; }
+        }
+    }
+    return now_ms() - t0;
 }
 
 void rto_quantize(const float* c, int64_t n, unsigned char* out) {

@@ -30,7 +30,17 @@ typedef struct rto_params {
                             1 = early exit (primary: stop once the nearest hit lies before the
                                 next voxel crossing; shadow: stop at the first passing triangle) */
     float early_slack;   /* relative slack on the early-exit comparison */
+    /* rto_render_rows_parallel only */
+    int32_t reflect_depth;   /* 3: REFLECT_DEPTH, Parallel/raytracer.cu:16 */
+    float shadow_bias;       /* 0.02f: Parallel/raytracer.cu:494 */
 } rto_params;
+
+/* Material table entry of the Parallel tree (Parallel/geometry.cuh:284-303). */
+typedef struct rto_material {
+    float base_color[3];
+    float kd, ks, spec_alpha, ka, km;
+    int32_t reflective;
+} rto_material;
 
 typedef struct rto_counters {
     uint64_t primary_rays, primary_entering, hits, shadow_rays, shadow_entering, shadowed;
@@ -43,6 +53,10 @@ rto_scene* rto_scene_create(void);
 void rto_scene_destroy(rto_scene* s);
 /* Restates load_mesh (Serial/raytracer.cpp:220-287). Returns triangles added, or <0 on a bad face index. */
 int64_t rto_scene_add_obj(rto_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]);
+/* Restates load_mesh of the Parallel tree (Parallel/raytracer.cu:805-873): vertex = scale * (coordinate + offset) in double,
+ * rounded to float, and a material. Meshes added through the colour-only calls get the Parallel tree's table entry 1. */
+int64_t rto_scene_add_obj_material(rto_scene* s, const char* path, int format_has_vt, const rto_material* m, const float offset[3], int scale);
+int64_t rto_scene_add_triangles_material(rto_scene* s, const float* v9, int64_t n, const rto_material* m);
 /* Adds n triangles given as 9 floats each (v0,v1,v2) with one colour. */
 int64_t rto_scene_add_triangles(rto_scene* s, const float* v9, int64_t n, const float color[3]);
 int64_t rto_scene_num_triangles(const rto_scene* s);
@@ -56,6 +70,13 @@ int64_t rto_grid_csr(const rto_scene* s, const uint32_t** cell_start, const uint
 /* Renders rows [y0,y1) of the frame: rgb (3 floats per pixel) and ids (primary-hit triangle or -1),
  * either may be NULL. counters (may be NULL) are ADDED to. Returns wall ms of the pixel loop. */
 double rto_render_rows(const rto_scene* s, const rto_params* p, int y0, int y1, float* rgb, int32_t* ids, rto_counters* counters);
+
+/* fast_trace of the PARALLEL tree (Parallel/raytracer.cu:445-524) with its hit rule (Parallel/geometry.cuh:123-170) and grid
+ * walk (Parallel/grid.cuh:224-290), on this scene's grid and camera conventions. PARITY UNPINNED: the Parallel tree is CUDA
+ * and cannot be compiled here, so this restatement has never been compared with the reference's own output. p->eps is the
+ * hit threshold (1e-4 there), p->shadow_scale the factor of a shadowed colour (0.5 there); kd, ks, ka, spec_alpha and
+ * light_intensity of p are unused (the materials carry them). walk_mode as in rto_render_rows. */
+double rto_render_rows_parallel(const rto_scene* s, const rto_params* p, int y0, int y1, float* rgb, int32_t* ids);
 
 /* The PPM quantisation of Serial/raytracer.cpp:181-183. */
 void rto_quantize(const float* c, int64_t n, unsigned char* out);

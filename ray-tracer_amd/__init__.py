@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_AMD_LIB", os.path.join(_HERE, "librt_amd.so"))   # override: A/B runs of two builds
 
 RT_WALK_EARLY, RT_WALK_FULL = 0, 1
+RT_SHADE_SERIAL, RT_SHADE_PARALLEL = 0, 1
 RT_BAND_ROWS = 8
 
 
@@ -33,7 +34,17 @@ class Params(C.Structure):
         ("spec_alpha", C.c_float), ("light_intensity", C.c_float), ("shadow_scale", C.c_float), ("eps", C.c_float),
         ("walk_mode", C.c_int32),
         ("part_index", C.c_int32), ("part_count", C.c_int32),
+        ("shading_mode", C.c_int32), ("reflect_depth", C.c_int32), ("shadow_bias", C.c_float),
     ]
+
+
+class Material(C.Structure):
+    """rt_material: one entry of the Parallel tree's material table (Parallel/geometry.cuh:284-303)."""
+    _fields_ = [("base_color", C.c_float * 3), ("kd", C.c_float), ("ks", C.c_float), ("spec_alpha", C.c_float), ("ka", C.c_float),
+                ("km", C.c_float), ("reflective", C.c_int32)]
+
+    def __init__(self, base_color=(255, 0, 0), kd=10.0, ks=10.0, spec_alpha=1.25, ka=0.3, km=0.0, reflective=False):
+        super().__init__((C.c_float * 3)(*[float(x) for x in base_color]), kd, ks, spec_alpha, ka, km, int(bool(reflective)))
 
 
 def _as_dict(st):
@@ -69,7 +80,7 @@ class FrameCounts(C.Structure):
 # every symbol include/rt_amd.h and include/rt_amd_diag.h declare
 EXPORTS = [
     "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
-    "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_num_triangles",
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_add_obj_material", "rt_scene_add_triangles_material", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
     "rt_render_device", "rt_render_device_noalloc", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_unit_costs",
     "rt_deinterleave_device", "rt_selftest_division", "rt_comm_create", "rt_comm_destroy", "rt_comm_size", "rt_gather_bands",
@@ -106,6 +117,10 @@ def lib():
     L.rt_scene_add_obj.restype = i64
     L.rt_scene_add_triangles.argtypes = [vp, vp, i64, vp]
     L.rt_scene_add_triangles.restype = i64
+    L.rt_scene_add_obj_material.argtypes = [vp, C.c_char_p, C.c_int, vp, vp, i32]
+    L.rt_scene_add_obj_material.restype = i64
+    L.rt_scene_add_triangles_material.argtypes = [vp, vp, i64, vp]
+    L.rt_scene_add_triangles_material.restype = i64
     L.rt_scene_num_triangles.argtypes = [vp]
     L.rt_scene_num_triangles.restype = i64
     L.rt_scene_get_triangles.argtypes = [vp, vp]
@@ -184,6 +199,14 @@ class Scene:
     def add_triangles(self, v9, mesh_color=(255, 0, 0)):
         v9 = np.ascontiguousarray(v9, dtype=np.float32).reshape(-1, 9)
         return _check(lib().rt_scene_add_triangles(self.h, v9.ctypes.data, v9.shape[0], _f3(mesh_color)))
+
+    # load_mesh(filename, triangle_list, format_has_vt, material_index, offset, scale) of the Parallel tree
+    def load_mesh_material(self, filename, format_has_vt, material, offset=(0, 0, 0), scale=1):
+        return _check(lib().rt_scene_add_obj_material(self.h, os.fsencode(filename), int(format_has_vt), C.byref(material), _f3(offset), int(scale)))
+
+    def add_triangles_material(self, v9, material):
+        v9 = np.ascontiguousarray(v9, dtype=np.float32).reshape(-1, 9)
+        return _check(lib().rt_scene_add_triangles_material(self.h, v9.ctypes.data, v9.shape[0], C.byref(material)))
 
     @property
     def num_triangles(self):

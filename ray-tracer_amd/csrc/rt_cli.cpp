@@ -10,12 +10,14 @@
 #include <string>
 #include <vector>
 
-struct MeshArg { std::string path; int has_vt; float color[3]; float offset[3]; };
+struct MeshArg { std::string path; int has_vt; float color[3]; float offset[3]; int scale; rt_material mat; bool has_mat; };
 
 static void usage() {
     fprintf(stderr,
             "usage: rt [--obj PATH [--no-vt] [--color R G B] [--offset X Y Z]]... [--size W H] [--out FILE]\n"
             "          [--cam X Y Z] [--target X Y Z] [--up X Y Z] [--fov DEG] [--full-walk] [--stats]\n"
+            "          [--parallel-shading [--light X Y Z] [--eps E] [--shadow-scale S] [--reflect-depth D]]\n"
+            "          per mesh: [--scale N] [--material KD KS ALPHA KA KM REFLECTIVE]   (fast_trace of the Parallel tree)\n"
             "       with no --obj: spot_triangulated.obj and blub_triangulated.obj (+1.5 in x) from the working directory\n");
 }
 
@@ -28,7 +30,20 @@ int main(int argc, char** argv) {
     auto need = [&](int i, int n) { if (i + n >= argc) { usage(); exit(2); } };
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
-        if (a == "--obj") { need(i, 1); MeshArg m{argv[++i], 1, {255, 0, 0}, {0, 0, 0}}; meshes.push_back(m); }
+        if (a == "--obj") { need(i, 1); MeshArg m{argv[++i], 1, {255, 0, 0}, {0, 0, 0}, 1, {}, false}; meshes.push_back(m); }
+        else if (a == "--scale" && !meshes.empty()) { need(i, 1); meshes.back().scale = atoi(argv[++i]); }
+        else if (a == "--material" && !meshes.empty()) {
+            need(i, 6);
+            rt_material& m = meshes.back().mat;
+            m.kd = (float)atof(argv[++i]); m.ks = (float)atof(argv[++i]); m.spec_alpha = (float)atof(argv[++i]); m.ka = (float)atof(argv[++i]);
+            m.km = (float)atof(argv[++i]); m.reflective = atoi(argv[++i]);
+            meshes.back().has_mat = true;
+        }
+        else if (a == "--parallel-shading") { p.shading_mode = RT_SHADE_PARALLEL; p.eps = 1e-4f; p.shadow_scale = 0.5f; }
+        else if (a == "--light") { need(i, 3); for (int k = 0; k < 3; ++k) p.light_pos[k] = (float)atof(argv[++i]); }
+        else if (a == "--eps") { need(i, 1); p.eps = (float)atof(argv[++i]); }
+        else if (a == "--shadow-scale") { need(i, 1); p.shadow_scale = (float)atof(argv[++i]); }
+        else if (a == "--reflect-depth") { need(i, 1); p.reflect_depth = atoi(argv[++i]); }
         else if (a == "--no-vt" && !meshes.empty()) meshes.back().has_vt = 0;
         else if (a == "--color" && !meshes.empty()) { need(i, 3); for (int k = 0; k < 3; ++k) meshes.back().color[k] = (float)atof(argv[++i]); }
         else if (a == "--offset" && !meshes.empty()) { need(i, 3); for (int k = 0; k < 3; ++k) meshes.back().offset[k] = (float)atof(argv[++i]); }
@@ -43,12 +58,19 @@ int main(int argc, char** argv) {
         else { usage(); return 2; }
     }
     if (meshes.empty()) {
-        meshes.push_back(MeshArg{"spot_triangulated.obj", 1, {255, 0, 0}, {0, 0, 0}});
-        meshes.push_back(MeshArg{"blub_triangulated.obj", 1, {255, 0, 0}, {1.5f, 0, 0}});
+        meshes.push_back(MeshArg{"spot_triangulated.obj", 1, {255, 0, 0}, {0, 0, 0}, 1, {}, false});
+        meshes.push_back(MeshArg{"blub_triangulated.obj", 1, {255, 0, 0}, {1.5f, 0, 0}, 1, {}, false});
     }
     rt_scene* s = rt_scene_create();
     for (auto& m : meshes) {
-        long long n = rt_scene_add_obj(s, m.path.c_str(), m.has_vt, m.color, m.offset);
+        long long n;
+        if (m.has_mat || m.scale != 1) {
+            if (!m.has_mat) { m.mat.kd = 10; m.mat.ks = 10; m.mat.spec_alpha = 1.25f; m.mat.ka = 0.3f; m.mat.km = 0; m.mat.reflective = 0; }
+            for (int k = 0; k < 3; ++k) m.mat.base_color[k] = m.color[k];
+            n = rt_scene_add_obj_material(s, m.path.c_str(), m.has_vt, &m.mat, m.offset, m.scale);
+        } else {
+            n = rt_scene_add_obj(s, m.path.c_str(), m.has_vt, m.color, m.offset);
+        }
         if (n < 0) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
     }
     int rc = rt_render_ppm(s, &p, out.c_str());

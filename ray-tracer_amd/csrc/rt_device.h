@@ -34,6 +34,10 @@ struct RtCamera {
 struct RtShade {
     float light[3];
     float kd, ks, ka, spec_alpha, light_intensity, shadow_scale, eps;
+    // second shading mode (fast_trace of the Parallel tree): per-mesh materials, shadow ray towards the light starting at
+    // eps + shadow_bias, mirror reflection down to reflect_depth
+    int32_t reflect_depth;
+    float shadow_bias;
 };
 
 struct RtFrame {
@@ -43,6 +47,7 @@ struct RtFrame {
     int32_t walk_full;            // 1 = walk every primary ray to the grid exit
     float early_slack;
     int32_t count_work;           // 1 = the kernel also counts voxel steps and triangle tests
+    int32_t shading_mode;         // 0 = fast_trace of the Serial tree, 1 = fast_trace of the Parallel tree
     uint64_t unit_shifts;         // 4 bits per queue list (list 0 lowest): log2 of the work units a tile of the list is cut into
     int32_t adapt_units;          // 1: k_bucket enlarges the units when the frame lists many tiles per wavefront
     int32_t cull_min;             // voxels with at least this many triangles get the per-run box test
@@ -56,6 +61,7 @@ struct RtSceneDev {
     const float4* v1;
     const float4* v2;
     const float* mesh_color;      // 3 floats per mesh
+    const float* mesh_mat;        // 8 floats per mesh: kd, ks, spec_alpha, ka, km, reflective (0 / 1), two unused (second shading mode)
     uint32_t n_tris;
     const RtGrid* grid;
     const uint32_t* cell_start;   // n_cells + 1

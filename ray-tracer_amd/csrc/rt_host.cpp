@@ -75,6 +75,7 @@ struct rt_scene {
     std::vector<float> tri;            // 9 floats per triangle: v0 v1 v2
     std::vector<uint32_t> tri_mesh;    // mesh index per triangle (one per load_mesh call)
     std::vector<float> mesh_color;     // 3 floats per mesh: Triangle::material
+    std::vector<float> mesh_mat;       // 8 floats per mesh: kd, ks, spec_alpha, ka, km, reflective, 0, 0 (second shading mode)
     // device state
     int device = -1;
     bool uploaded = false;
@@ -84,7 +85,7 @@ struct rt_scene {
     bool build_clean = false;          // the last grid build ran to its end and left its counters reset for the next one
     DevBuf<float4> v0, v1, v2, tri_rec;
     DevBuf<float2> tri_box;
-    DevBuf<float> d_mesh_color;
+    DevBuf<float> d_mesh_color, d_mesh_mat;
     DevBuf<RtGrid> d_grid;
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
     DevBuf<uint2> row_minmax;
@@ -168,7 +169,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->device >= 0) {
         (void)hipSetDevice(s->device);
-        s->v0.release(); s->v1.release(); s->v2.release(); s->tri_rec.release(); s->tri_box.release(); s->d_mesh_color.release(); s->d_grid.release();
+        s->v0.release(); s->v1.release(); s->v2.release(); s->tri_rec.release(); s->tri_box.release(); s->d_mesh_color.release(); s->d_mesh_mat.release(); s->d_grid.release();
         s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
         s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->row_minmax.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); s->queue_lists.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
@@ -182,11 +183,24 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
 
 static void scene_touch(rt_scene* s) { s->uploaded = false; s->grid_valid = false; s->refs_known = false; s->build_clean = false; }
 
-static int64_t add_triangles_impl(rt_scene* s, const float* v9, int64_t n, const float color[3]) {
-    if (!s || n < 0 || (n > 0 && !v9) || !color) return set_err(RT_ERR_INVALID, "rt_scene_add_triangles: bad argument");
+// entry 1 of the Parallel tree's material table (Parallel/raytracer.cu:451) around a given colour
+static rt_material default_material(const float color[3]) {
+    rt_material m;
+    for (int a = 0; a < 3; ++a) m.base_color[a] = color[a];
+    m.kd = 10.0f; m.ks = 10.0f; m.spec_alpha = 1.25f; m.ka = 0.3f; m.km = 0.f; m.reflective = 0;
+    return m;
+}
+static void push_mesh(rt_scene* s, const rt_material& m) {
+    s->mesh_color.insert(s->mesh_color.end(), m.base_color, m.base_color + 3);
+    const float mat[8] = {m.kd, m.ks, m.spec_alpha, m.ka, m.km, m.reflective ? 1.f : 0.f, 0.f, 0.f};
+    s->mesh_mat.insert(s->mesh_mat.end(), mat, mat + 8);
+}
+
+static int64_t add_triangles_impl(rt_scene* s, const float* v9, int64_t n, const rt_material* mat) {
+    if (!s || n < 0 || (n > 0 && !v9) || !mat) return set_err(RT_ERR_INVALID, "rt_scene_add_triangles: bad argument");
     if ((uint64_t)s->tri_mesh.size() + (uint64_t)n >= 0x7fffffffull) return set_err(RT_ERR_INVALID, "too many triangles");
     uint32_t mesh = (uint32_t)(s->mesh_color.size() / 3);
-    s->mesh_color.insert(s->mesh_color.end(), color, color + 3);
+    push_mesh(s, *mat);
     s->tri.insert(s->tri.end(), v9, v9 + 9 * n);
     s->tri_mesh.insert(s->tri_mesh.end(), (size_t)n, mesh);
     scene_touch(s);
@@ -194,7 +208,12 @@ static int64_t add_triangles_impl(rt_scene* s, const float* v9, int64_t n, const
 }
 
 extern "C" int64_t rt_scene_add_triangles(rt_scene* s, const float* v9, int64_t n, const float color[3]) {
-    RT_GUARD(int64_t, add_triangles_impl(s, v9, n, color))
+    if (!color) return set_err(RT_ERR_INVALID, "rt_scene_add_triangles: bad argument");
+    const rt_material m = default_material(color);
+    RT_GUARD(int64_t, add_triangles_impl(s, v9, n, &m))
+}
+extern "C" int64_t rt_scene_add_triangles_material(rt_scene* s, const float* v9, int64_t n, const rt_material* material) {
+    RT_GUARD(int64_t, add_triangles_impl(s, v9, n, material))
 }
 
 extern "C" int64_t rt_scene_num_triangles(const rt_scene* s) { return s ? (int64_t)s->tri_mesh.size() : 0; }
@@ -213,9 +232,10 @@ extern "C" int rt_scene_get_triangles(const rt_scene* s, float* v9) {
 
 static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
 
-static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]) {
+static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, const rt_material* mat, const float offset[3], int32_t scale_i) {
     (void)format_has_vt;   // the texture index is parsed by the reference but never used by the path
-    if (!s || !path || !color || !offset) return set_err(RT_ERR_INVALID, "rt_scene_add_obj: bad argument");
+    if (!s || !path || !mat || !offset) return set_err(RT_ERR_INVALID, "rt_scene_add_obj: bad argument");
+    const double scale = (double)scale_i;      // Parallel/raytracer.cu:824: scale * (a + offset.x), an int times a double; 1 for the Serial loader
     FILE* f = fopen(path, "rb");
     if (!f) return 0;   // like the reference: a missing file is an empty mesh
     // a directory, a pipe or any other path that cannot be sized and read whole is an I/O error, not an empty mesh
@@ -258,9 +278,9 @@ static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, co
                 c[k] = d;
                 r = e;
             }
-            verts.push_back((float)(c[0] + off[0]));
-            verts.push_back((float)(c[1] + off[1]));
-            verts.push_back((float)(c[2] + off[2]));
+            verts.push_back((float)(scale * (c[0] + off[0])));      // times 1.0 is exact: the Serial loader's value
+            verts.push_back((float)(scale * (c[1] + off[1])));
+            verts.push_back((float)(scale * (c[2] + off[2])));
         } else if (t - q == 1 && *q == 'f') {
             long idx[3] = {0, 0, 0};
             char* r = t;
@@ -288,19 +308,27 @@ static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, co
         *le = saved;
         p = nl ? nl + 1 : end;
     }
-    s->mesh_color.insert(s->mesh_color.end(), color, color + 3);
+    push_mesh(s, *mat);
     scene_touch(s);
     return (int64_t)(s->tri_mesh.size() - tri_before);
 }
 
-extern "C" int64_t rt_scene_add_obj(rt_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]) {
-    const size_t tris_before = s ? s->tri_mesh.size() : 0, meshes_before = s ? s->mesh_color.size() : 0;
-    try { return add_obj_impl(s, path, format_has_vt, color, offset); }
+static int64_t add_obj_guarded(rt_scene* s, const char* path, int format_has_vt, const rt_material* mat, const float offset[3], int32_t scale) {
+    const size_t tris_before = s ? s->tri_mesh.size() : 0, meshes_before = s ? s->mesh_color.size() / 3 : 0;
+    try { return add_obj_impl(s, path, format_has_vt, mat, offset, scale); }
     catch (...) {
         // out of memory half way through the file: the triangle list is left as it was
-        if (s) { s->tri.resize(tris_before * 9); s->tri_mesh.resize(tris_before); s->mesh_color.resize(meshes_before); }
+        if (s) { s->tri.resize(tris_before * 9); s->tri_mesh.resize(tris_before); s->mesh_color.resize(meshes_before * 3); s->mesh_mat.resize(meshes_before * 8); }
         return set_err(RT_ERR_NOMEM, "out of host memory while reading %s", path ? path : "(null)");
     }
+}
+extern "C" int64_t rt_scene_add_obj(rt_scene* s, const char* path, int format_has_vt, const float color[3], const float offset[3]) {
+    if (!color) return set_err(RT_ERR_INVALID, "rt_scene_add_obj: bad argument");
+    const rt_material m = default_material(color);
+    return add_obj_guarded(s, path, format_has_vt, &m, offset, 1);
+}
+extern "C" int64_t rt_scene_add_obj_material(rt_scene* s, const char* path, int format_has_vt, const rt_material* material, const float offset[3], int32_t scale) {
+    return add_obj_guarded(s, path, format_has_vt, material, offset, scale);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,6 +347,7 @@ extern "C" void rt_params_default(rt_params* p) {
     p->eps = 1e-1f;
     p->walk_mode = RT_WALK_EARLY;
     p->part_index = 0; p->part_count = 1;
+    p->shading_mode = RT_SHADE_SERIAL; p->reflect_depth = 3; p->shadow_bias = 0.02f;
 }
 
 extern "C" int32_t rt_part_rows(const rt_params* p) {
@@ -502,6 +531,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     const size_t Tn = T ? T : 1;
     if ((rc = s->v0.ensure(Tn)) || (rc = s->v1.ensure(Tn)) || (rc = s->v2.ensure(Tn)) || (rc = s->tri_rec.ensure(3 * Tn)) || (rc = s->tri_box.ensure(3 * Tn))) return rc;
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
+    if ((rc = s->d_mesh_mat.ensure(s->mesh_mat.size() ? s->mesh_mat.size() : 8))) return rc;
     if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
         (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
         (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(RT_COUNTER_WORDS)))
@@ -526,8 +556,10 @@ extern "C" int rt_scene_upload(rt_scene* s) {
         stage.release(); stage_mesh.release();
         if (e != hipSuccess) return set_err(RT_ERR_HIP, "scene upload: %s", hipGetErrorString(e));
     }
-    if (!s->mesh_color.empty())
+    if (!s->mesh_color.empty()) {
         HIP_TRY(hipMemcpy(s->d_mesh_color.p, s->mesh_color.data(), s->mesh_color.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->d_mesh_mat.p, s->mesh_mat.data(), s->mesh_mat.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     s->uploaded = true;
     s->grid_valid = false;
     s->build_clean = false;
@@ -634,6 +666,9 @@ static int check_params(const rt_params* p) {
     if (p->width <= 0 || p->height <= 0 || p->width > 65536 || p->height > 65536) return set_err(RT_ERR_INVALID, "bad frame size %dx%d", p->width, p->height);
     if (p->part_count < 1 || p->part_index < 0 || p->part_index >= p->part_count) return set_err(RT_ERR_INVALID, "bad partition %d/%d", p->part_index, p->part_count);
     if (p->walk_mode != RT_WALK_EARLY && p->walk_mode != RT_WALK_FULL) return set_err(RT_ERR_INVALID, "bad walk_mode %d", p->walk_mode);
+    if (p->shading_mode != RT_SHADE_SERIAL && p->shading_mode != RT_SHADE_PARALLEL) return set_err(RT_ERR_INVALID, "bad shading_mode %d", p->shading_mode);
+    if (p->shading_mode == RT_SHADE_PARALLEL && (p->reflect_depth < 0 || p->reflect_depth > 3 || !isfinite(p->shadow_bias)))
+        return set_err(RT_ERR_INVALID, "bad reflect_depth %d (0..3) or shadow_bias", p->reflect_depth);
     // The reference has no such check (its parameters are literals); a non-finite camera, light or constant gives NaN rays
     // and NaN hit distances, for which its own result is undefined (it reads a stale triangle pointer).
     if (!finite3(p->cam_pos) || !finite3(p->cam_target) || !finite3(p->cam_up) || !finite3(p->light_pos) || !isfinite(p->fov) || !isfinite(p->kd) ||
@@ -712,12 +747,14 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
     sd.mesh_color = s->d_mesh_color.p;
+    sd.mesh_mat = s->d_mesh_mat.p;
     sd.n_tris = (uint32_t)s->n_tris();
     sd.grid = m.grid; sd.cell_start = m.cell_start; sd.occupancy = m.occupancy; sd.recs = m.recs; sd.blk_bounds = m.blk_bounds;
     RtShade sh;
     for (int a = 0; a < 3; ++a) sh.light[a] = p->light_pos[a];
     sh.kd = p->kd; sh.ks = p->ks; sh.ka = p->ka; sh.spec_alpha = p->spec_alpha;
     sh.light_intensity = p->light_intensity; sh.shadow_scale = p->shadow_scale; sh.eps = p->eps;
+    sh.reflect_depth = p->reflect_depth; sh.shadow_bias = p->shadow_bias;
     RtFrame f;
     f.width = p->width; f.height = p->height;
     f.part_index = p->part_index; f.part_count = p->part_count;
@@ -725,6 +762,8 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
     f.walk_full = (p->walk_mode == RT_WALK_FULL);
     f.early_slack = 0.f;
     f.count_work = counting ? 1 : 0;
+    f.shading_mode = p->shading_mode;
+    if (counting && p->shading_mode != RT_SHADE_SERIAL) return set_err(RT_ERR_INVALID, "the counting build of the render kernel exists for RT_SHADE_SERIAL only");
     // A grid has at most RT_MAX_CELLS voxels: from two references per voxel on average it is crowded for certain, and the
     // trace kernel without the path for voxels of a few records is used.
     f.own_path = (s->known_refs >= 2u * (uint32_t)RT_MAX_CELLS) ? 0 : 1;

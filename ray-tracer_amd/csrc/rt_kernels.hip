@@ -1421,10 +1421,17 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 //   gnum  = e1.x*P(s,d)  -  s.x*P(e1,d) + d.x*P(e1,s)
 // The divisions are only executed when the signs allow beta > 0 and gamma > 0 and the numerators allow
 // beta + gamma < 1 with a 1e-12 relative margin; inside that margin the reference's own expression decides.
-template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT, bool OWN>
+// RULE selects the hit rule. 0: Triangle::Intersect of the Serial tree as described above. 1: the one of the Parallel tree
+// (Parallel/geometry.cuh:123-170): a passing triangle counts only if eps < t < t_min, with t_min a double that is never
+// rounded, so the nearest hit is the plain minimum (ties: earlier voxel, then lower index) and a shadow query is true only
+// for passing triangles beyond eps. With RULE 1 `td` carries the nearest distance; st.t is kept at td rounded up to float
+// for the early-exit comparison (never stops a ray the exact comparison would not stop), st.id is the nearest triangle.
+template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT, bool OWN, int RULE = 0>
 __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* bitmap, int lane, bool active, float ox,
                                           float oy, float oz, float dx, float dy, float dz, float mint, bool use_eps, float eps,
-                                          bool early, float slack, uint32_t cull_min, int ray_lanes, Nearest& st, WalkCount& wc) {
+                                          bool early, float slack, uint32_t cull_min, int ray_lanes, Nearest& st, WalkCount& wc,
+                                          double* td = nullptr) {
+    static_assert(RULE == 0 || !OWN, "the Parallel tree's hit rule is only built into the streamed test path");
     Dda w;
     bool alive = false;
     if (__ballot(active)) {
@@ -1477,6 +1484,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         unsigned long long need0 = ~0ull, need1 = ~0ull, any0 = ~0ull, any1 = ~0ull;
         VoxelBest vb;                                    // passing triangles of this round's voxel (primary rays)
         vb_reset(vb);
+        double pb_t = INFINITY;                          // RULE 1: nearest passing triangle beyond eps of this round's voxel
+        int pb_id = -1;
         // FP32 test of a ray's whole line against a run's box and slab (k_block_bounds): the parameter interval in which
         // the line is inside the box must overlap the one in which it is between the slab's planes. Box faces and slab
         // planes are moved outwards by mg = 4e-6 (8e-6 for the slab) * (largest |coordinate| of the box + |origin|), more
@@ -1757,7 +1766,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                             gamma = gnum / A;
                         }
                         pm = cand & __builtin_amdgcn_fcmp(beta, 0.0, 2) & __builtin_amdgcn_fcmp(gamma, 0.0, 2) & __builtin_amdgcn_fcmp(beta + gamma, 1.0, 4);
-                        if (!ANY_HIT && pm) {
+                        if ((!ANY_HIT || RULE == 1) && pm) {
                             const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
                             const uint32_t et = exponent_field(tnum);
                             if (fast && (pm & ~(__builtin_amdgcn_uicmp(et, RT_DIV_EXP_LO, 35) & __builtin_amdgcn_uicmp(et, RT_DIV_EXP_HI, 37))) == 0ull) {
@@ -1767,6 +1776,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                             }
                         }
                     }
+                    if (RULE == 1 && ANY_HIT) pm &= __builtin_amdgcn_fcmp(tt, (double)eps, 2) & __builtin_amdgcn_fcmp(tt, (double)INFINITY, 4);
                     if (pm) {
                         if (ANY_HIT) {
                             if (lane == i) {
@@ -1774,14 +1784,18 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                                 if (COUNT) wc.tests -= e - (base + (uint32_t)__ffsll((long long)pm));   // tests the reference order skips
                             }
                         } else {
-                            if (lane == i) hit = true;
+                            if (RULE == 0 && lane == i) hit = true;
                             // the passing triangles go into the ray's summary of this voxel visit (any order)
                             while (pm) {
                                 const int pl = __ffsll((long long)pm) - 1;
                                 pm &= pm - 1;
                                 const double t_p = bcast_f64(tt, pl);
                                 const int id_p = __builtin_amdgcn_readlane((int)t.id, pl);
-                                if (lane == i && (!use_eps || t_p > (double)eps)) vb_add(vb, t_p, id_p);
+                                if (RULE == 0) {
+                                    if (lane == i && (!use_eps || t_p > (double)eps)) vb_add(vb, t_p, id_p);
+                                } else if (lane == i && t_p > (double)eps && (t_p < pb_t || (t_p == pb_t && id_p < pb_id))) {
+                                    pb_t = t_p; pb_id = id_p;
+                                }
                             }
                         }
                     }
@@ -1811,7 +1825,11 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 process(cur, t);
             }
         }
-        if (!ANY_HIT) vb_apply(vb, st);
+        if (!ANY_HIT && RULE == 0) vb_apply(vb, st);
+        if (!ANY_HIT && RULE == 1 && pb_t < *td) {       // strict: an equal distance found in an earlier voxel stays
+            *td = pb_t; st.id = pb_id; hit = true;
+            st.t = __double2float_ru(pb_t);
+        }
         if (COUNT) wc.cyc_test += (uint32_t)((long long)__builtin_amdgcn_s_memtime() - t2);
     }
     return hit;
@@ -1832,7 +1850,102 @@ struct RtTraceArgs {
     uint32_t list_cap;
 };
 
-template <bool COUNT, bool OWN>
+// fast_trace of the Parallel tree (Parallel/raytracer.cu:445-524) for the rays of one work unit: nearest hit by the
+// Parallel tree's rule, Blinn-Phong with the hit mesh's material and the unnormalised normal (v2-v1)x(v0-v1), a shadow ray
+// TOWARDS the light from eps + bias that halves (shadow_scale) the whole colour, and for reflective materials a mirror ray
+// from the hit point, down to reflect_depth levels: colour = (colour * base) * (1 - km) + reflected * km. The recursion is
+// run as a loop; the levels' terms are kept and folded from the deepest level outwards, which is the order in which the
+// recursion adds them. Vector normalisation as everywhere in this file (float length, double sqrt).
+// The Parallel tree cannot be compiled here (CUDA), so this mode is checked against a CPU restatement only.
+template <bool COUNT>
+__device__ __forceinline__ void trace_unit_parallel(const RtSceneDev& s, const RtCamera& cam, const RtShade& sh, const RtFrame& f, const uint32_t* bitmap,
+                                                    int lane, bool live, float dx, float dy, float dz, int per_unit, float& out_r, float& out_g,
+                                                    float& out_b, int& out_id, bool& out_hit, bool& out_shadowed) {
+    constexpr int MAXD = 4;                      // primary ray + at most three reflections (REFLECT_DEPTH, Parallel/raytracer.cu:16)
+    float Ar[MAXD], Ag[MAXD], Ab[MAXD], Km[MAXD];
+#pragma unroll
+    for (int k = 0; k < MAXD; ++k) { Ar[k] = 0.f; Ag[k] = 0.f; Ab[k] = 0.f; Km[k] = 0.f; }
+    const int depth = f.shading_mode == 1 ? (sh.reflect_depth < 0 ? 0 : (sh.reflect_depth > MAXD - 1 ? MAXD - 1 : sh.reflect_depth)) : 0;
+    float ox = cam.pos[0], oy = cam.pos[1], oz = cam.pos[2];
+    Nearest st = {INFINITY, -1};
+    double td = INFINITY;
+    WalkCount wc = {};
+    bool cur = wave_walk<false, true, COUNT, false, 1>(s, bitmap, lane, live, ox, oy, oz, dx, dy, dz, 0.f, true, sh.eps, f.walk_full == 0,
+                                                        f.early_slack, (uint32_t)f.cull_min, per_unit, st, wc, &td);
+    cur = cur && st.id >= 0;
+    out_id = cur ? st.id : -1;
+    out_hit = cur;
+    out_shadowed = false;
+#pragma nounroll
+    for (int d = 0; d < MAXD; ++d) {        // one copy of the walks in the code: the levels' terms live in scratch memory
+        if (d > depth || !__ballot(cur)) break;
+        float colr = 0.f, colg = 0.f, colb = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, km = 0.f;
+        float poix = 0.f, poiy = 0.f, poiz = 0.f, lx = 0.f, ly = 0.f, lz = 1.f, nx = 0.f, ny = 0.f, nz = 0.f;
+        bool reflective = false;
+        if (cur) {
+            const float4 p0 = s.v0[st.id], p1 = s.v1[st.id], p2 = s.v2[st.id];
+            const uint32_t mesh = __float_as_uint(p0.w);
+            colr = s.mesh_color[3 * mesh]; colg = s.mesh_color[3 * mesh + 1]; colb = s.mesh_color[3 * mesh + 2];
+            const float* m = s.mesh_mat + 8 * mesh;
+            const float kd = m[0], ks = m[1], alpha = m[2], ka = m[3];
+            km = m[4];
+            reflective = m[5] != 0.f && d < depth;
+            const float tn = (float)td;                              // Vec3f::scale takes a float
+            poix = ox + dx * tn; poiy = oy + dy * tn; poiz = oz + dz * tn;
+            float vx = -dx, vy = -dy, vz = -dz;
+            normalize3(vx, vy, vz);
+            lx = sh.light[0] - poix; ly = sh.light[1] - poiy; lz = sh.light[2] - poiz;
+            normalize3(lx, ly, lz);
+            float hx = vx + lx, hy = vy + ly, hz = vz + lz;
+            normalize3(hx, hy, hz);
+            // normal = (v2 - v1) x (v0 - v1), Parallel/geometry.cuh:160
+            const float ax = p2.x - p1.x, ay = p2.y - p1.y, az = p2.z - p1.z;
+            const float bx = p0.x - p1.x, by = p0.y - p1.y, bz = p0.z - p1.z;
+            nx = ay * bz - az * by; ny = az * bx - ax * bz; nz = ax * by - ay * bx;
+            const float fd = max_std(0.f, nx * lx + ny * ly + nz * lz);
+            const float fs = powf(max_std(0.f, nx * hx + ny * hy + nz * hz), alpha);
+            cr = ((colr * fd) * kd + (colr * fs) * ks) + colr * ka;
+            cg = ((colg * fd) * kd + (colg * fs) * ks) + colg * ka;
+            cb = ((colb * fd) * kd + (colb * fs) * ks) + colb * ka;
+        }
+        // shadow ray towards the light, Parallel/raytracer.cu:492-506 (the light's direction is l again)
+        Nearest sst = {INFINITY, -1};
+        const bool shadowed = wave_walk<true, false, COUNT, false, 1>(s, bitmap, lane, cur, poix, poiy, poiz, lx, ly, lz, sh.eps + sh.shadow_bias, true,
+                                                                   sh.eps, true, 0.f, (uint32_t)f.cull_min, per_unit, sst, wc);
+        if (d == 0) out_shadowed = shadowed;
+        float rx = 0.f, ry = 0.f, rz = 1.f;
+        if (cur) {
+            if (shadowed) { cr = cr * sh.shadow_scale; cg = cg * sh.shadow_scale; cb = cb * sh.shadow_scale; }
+            if (reflective) {
+                Ar[d] = (cr * colr) * (1 - km); Ag[d] = (cg * colg) * (1 - km); Ab[d] = (cb * colb) * (1 - km);
+                Km[d] = km;
+                // reflect(raydir.normalize(), normal.normalize()).normalize(), Parallel/raytracer.cu:509,875-878
+                float ix = dx, iy = dy, iz = dz;
+                normalize3(ix, iy, iz);
+                normalize3(nx, ny, nz);
+                const float factor = (ix * nx + iy * ny + iz * nz) * 2;
+                rx = ix - nx * factor; ry = iy - ny * factor; rz = iz - nz * factor;
+                normalize3(rx, ry, rz);
+            } else {
+                Ar[d] = cr; Ag[d] = cg; Ab[d] = cb;
+            }
+        }
+        const bool next = cur && reflective;
+        if (d + 1 >= MAXD || d + 1 > depth) break;
+        if (next) { ox = poix; oy = poiy; oz = poiz; dx = rx; dy = ry; dz = rz; }
+        st.t = INFINITY; st.id = -1; td = INFINITY;
+        const bool h = wave_walk<false, false, COUNT, false, 1>(s, bitmap, lane, next, ox, oy, oz, dx, dy, dz, sh.eps, true, sh.eps, f.walk_full == 0,
+                                                               f.early_slack, (uint32_t)f.cull_min, per_unit, st, wc, &td);
+        cur = next && h && st.id >= 0;              // a reflected ray that hits nothing contributes Vec3f(0): A stays 0
+    }
+    // fold: level d's colour = A[d] + (level d+1's colour) * km[d]
+    float Rr = Ar[MAXD - 1], Rg = Ag[MAXD - 1], Rb = Ab[MAXD - 1];
+#pragma unroll
+    for (int k = MAXD - 2; k >= 0; --k) { Rr = Ar[k] + Rr * Km[k]; Rg = Ag[k] + Rg * Km[k]; Rb = Ab[k] + Rb * Km[k]; }
+    out_r = Rr; out_g = Rg; out_b = Rb;
+}
+
+template <bool COUNT, bool OWN, int MODE = 0>
 __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArgs args_in_kernarg_segment) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -1904,6 +2017,14 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
         float dx = 0.f, dy = 0.f, dz = 1.f;
         if (live) primary_ray(cam, f, x, y, dx, dy, dz);
 
+        float cr = 0.f, cg = 0.f, cb = 0.f;
+        int id = -1;
+        if constexpr (MODE == 1) {
+            bool hit = false, shadowed = false;
+            trace_unit_parallel<COUNT>(s, cam, sh, f, bitmap, lane, live, dx, dy, dz, per_unit, cr, cg, cb, id, hit, shadowed);
+            acc_hits += (uint32_t)__popcll(__ballot(hit));
+            acc_shadowed += (uint32_t)__popcll(__ballot(shadowed));
+        } else {
         // fast_trace, Serial/raytracer.cpp:71-118
         Nearest st = {INFINITY, -1};
         WalkCount wp = {}, ws = {};
@@ -1911,10 +2032,8 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
         const unsigned long long rt_start = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
         const bool hit_any = wave_walk<false, true, COUNT, OWN>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
                                                        sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, per_unit, st, wp);
-        float cr = 0.f, cg = 0.f, cb = 0.f;
         float colr = 0.f, colg = 0.f, colb = 0.f;
         float poix = 0.f, poiy = 0.f, poiz = 0.f, sx = 0.f, sy = 0.f, sz = 1.f;
-        int id = -1;
         // A triangle can pass the barycentric test with a hit distance that is NaN or +inf (overflowing coordinates): the
         // reference then shades whatever triangle an earlier pixel left in its global; here such a pixel stays background.
         const bool hit = hit_any && st.id >= 0;
@@ -1988,6 +2107,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
                     o.unit_info[3 * n16 + slot] = (c_t > 0xffffffu ? 0xffffffu : c_t) | ((wp.rounds + ws.rounds > 255u ? 255u : wp.rounds + ws.rounds) << 24);
                 }
             }
+        }
         }
         if (in_unit) write_pixel(f, o, x, y_local, cr, cg, cb, id);
     }
@@ -2067,7 +2187,9 @@ hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, Rt
     RtTraceArgs ta;
     ta.s = s; ta.cam = cam; ta.sh = sh; ta.f = f; ta.o = o; ta.work = wk.work;
     ta.lists = wk.lists; ta.list_cap = wk.list_cap;
-    if (f.count_work) {
+    if (f.shading_mode == 1) {
+        k_trace<false, false, 1><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+    } else if (f.count_work) {
         if (f.own_path) k_trace<true, true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
         else k_trace<true, false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     } else {
