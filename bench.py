@@ -62,8 +62,8 @@ def build_workload(rt, name):
         s.load_mesh(path)
         os.remove(path)
         return s, {}, 3840, 2160, "plane_mesh_creator SQUARES_PER_UNIT=100 (2,004,002 triangles) 3840x2160"
-    if name in ("nefertiti4k", "nefertiti8k"):
-        W, H = (3840, 2160) if name == "nefertiti4k" else (7680, 4320)
+    if name in ("nefertiti4k", "nefertiti8k", "nefertiti4k_close"):
+        W, H = (7680, 4320) if name == "nefertiti8k" else (3840, 2160)
         real = os.environ.get("RT_NEFERTITI_OBJ", "")
         if real and os.path.exists(real):
             s.load_mesh(real, False)
@@ -74,7 +74,10 @@ def build_workload(rt, name):
         v9 = rt.subdivide(tmp.triangles(), k)
         tmp.close()
         s.add_triangles(v9)
-        return s, {}, W, H, "nefertiti STAND-IN (mesh absent): blub_triangulated.obj midpoint-subdivided %dx = %d triangles, %dx%d" % (k, v9.shape[0], W, H)
+        label = "nefertiti STAND-IN (mesh absent): blub_triangulated.obj midpoint-subdivided %dx = %d triangles, %dx%d" % (k, v9.shape[0], W, H)
+        if name == "nefertiti4k_close":      # the traversal-stress camera as a workload of its own (profiling)
+            return s, dict(STRESS_CAMERA), W, H, label + ", close camera %s" % (STRESS_CAMERA["cam_pos"],)
+        return s, {}, W, H, label
     raise SystemExit("unknown workload " + name)
 
 
@@ -144,6 +147,8 @@ def main():
     ap.add_argument("--walk", default="early", choices=["early", "full"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-rebuild", action="store_true", help="reuse the grid (render-only frames)")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("RT_BENCH_IN_FLIGHT", "4")),
+                    help="frames in flight: frame k is issued on stream k %% D, each stream with its own working set in the scene (1 = one frame at a time)")
     ap.add_argument("--no-extras", action="store_true", help="headline frames only: no host-writeback loop, no stress camera (profiling runs: every "
                                                                 "launch of the trace kernel is then one of the timed frame's)")
     args = ap.parse_args()
@@ -177,40 +182,39 @@ def main():
     p = rt.default_params(W, H, walk_mode=walk, part_index=rank, part_count=world, **pkw)
     rows = rt.part_rows(p)
     dev = torch.device("cuda", local_rank)
-    part_u8 = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
-    frame_u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
-    gathered = torch.empty((world, rows, W, 3), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
     scene.upload()          # triangles resident in HBM before anything is timed
 
-    # N > 1: the exchange (gather to rank 0 + band de-interleave there) of frame k runs on a stream of its own beside the
-    # grid build and the trace of frame k + 1; two band buffers take turns. The frame rate is then that of the slower of
-    # the two pipelines instead of their sum.
-    main_stream = torch.cuda.current_stream()
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    part_bufs = [part_u8, torch.empty_like(part_u8)] if world > 1 else [part_u8]
-    ev_rendered = [torch.cuda.Event() for _ in part_bufs]
-    ev_exchanged = [torch.cuda.Event() for _ in part_bufs]
+    # Frames in flight: a frame is a dozen dependent kernels, the first ones short and narrow, the last one ending in a tail
+    # of a few long wavefronts, so one frame at a time leaves much of the GPU idle. Frame k is issued on lane k % D: a
+    # stream of its own (checked by the library to run beside the others) with its own working set in the scene and its own
+    # output buffers; everything of a frame, the exchange for N > 1 included (gather to rank 0 + band de-interleave there),
+    # is ordered by its lane's stream, and lanes overlap on the GPU. Every frame still builds its own grid.
+    depth = max(1, min(args.in_flight, 8))
+    scene.set_frames_in_flight(depth)
+    lane_handles = rt.create_streams(depth)
+    lanes = [torch.cuda.ExternalStream(h, device=dev) for h in lane_handles]
+    n_lanes = len(lanes)
+    part_bufs = [torch.empty((rows, W, 3), dtype=torch.uint8, device=dev) for _ in lanes]
+    part_u8 = part_bufs[0]
+    frame_bufs = [torch.empty((H, W, 3), dtype=torch.uint8, device=dev) for _ in lanes] if rank == 0 else None
+    gathered = [torch.empty((world, rows, W, 3), dtype=torch.uint8, device=dev) for _ in lanes] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
 
     def step(k):
-        b = k % len(part_bufs)
-        if world > 1 and k >= len(part_bufs):
-            main_stream.wait_event(ev_exchanged[b])             # the gather of frame k - 2 has read this band buffer
-        scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[b].data_ptr(), stream=stream)
+        b = k % n_lanes
+        scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[b].data_ptr(), stream=lane_handles[b])
         if world > 1:
-            ev_rendered[b].record(main_stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev_rendered[b])
+            with torch.cuda.stream(lanes[b]):
                 if rehearsal:
-                    comm_stream.synchronize()
+                    lanes[b].synchronize()
                     g = gather_parts(part_bufs[b].cpu(), world, rank)
                     if rank == 0:
-                        gathered.copy_(g)
+                        gathered[b].copy_(g)
                 else:
-                    gather_parts(part_bufs[b], world, rank, out=gathered)
+                    gather_parts(part_bufs[b], world, rank, out=gathered[b] if rank == 0 else None)
                 if rank == 0:
-                    rt.deinterleave_device(p, gathered.data_ptr(), frame_u8.data_ptr(), 3, stream=comm_stream.cuda_stream)
-                ev_exchanged[b].record(comm_stream)
+                    rt.deinterleave_device(p, gathered[b].data_ptr(), frame_bufs[b].data_ptr(), 3, stream=lane_handles[b])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -232,13 +236,24 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
 
-    # per-kernel device times of the timed frames (hipEvents recorded by the library on this stream)
+    # device times of the timed frames (clock values the frame's kernels write). With frames in flight a frame shares the
+    # GPU with its neighbours: its build and trace kernel take longer than alone, and their sum is the frame's latency.
     n_ev = min(args.steps, 120)
     st = [scene.stats_at(i) for i in range(n_ev)]
     ms_render = float(np.mean([x["ms_render"] for x in st]))
     ms_build = float(np.mean([x["ms_build"] for x in st]))
     hits_local = st[0]["hits"]
     rays_local = st[0]["primary_rays"] + hits_local
+    # the same frame alone on the GPU: a few frames one after the other on one lane (untimed by the driver)
+    ms_render_alone, ms_build_alone = ms_render, ms_build
+    if n_lanes > 1:
+        n_alone = max(3, min(args.steps, 10))
+        for _ in range(n_alone):
+            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
+        torch.cuda.synchronize()
+        st_a = [scene.stats_at(i) for i in range(n_alone - 1)]
+        ms_render_alone = float(np.mean([x["ms_render"] for x in st_a]))
+        ms_build_alone = float(np.mean([x["ms_build"] for x in st_a]))
 
     # N > 1: the gathered, de-interleaved frame must be the frame one GPU renders alone (untimed check on rank 0)
     frame_check = None
@@ -247,7 +262,7 @@ def main():
         single = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         scene.render_device(p1, rebuild_grid=False, d_u8=single.data_ptr(), stream=stream)
         torch.cuda.synchronize()
-        frame_check = bool(torch.equal(single, frame_u8))
+        frame_check = bool(torch.equal(single, frame_bufs[(args.steps - 1) % n_lanes]))
         del single
 
     # one extra, untimed frame with the counting kernel: voxel steps and triangle tests actually needed
@@ -262,31 +277,24 @@ def main():
     # grid build; two device and two host buffers. Single GPU only (on N GPUs rank 0 holds the gathered frame).
     wb = None
     if world == 1 and not args.no_extras:
-        copy_stream = torch.cuda.Stream(device=dev)
-        n_buf = int(os.environ.get("RT_WB_BUFFERS", "3"))
+        n_buf = n_lanes
+        # the copy of a frame follows its trace on the frame's lane, beside the other lanes' frames
         # small frames: a copy kernel that writes the mapped host buffer; large ones: hipMemcpyAsync (measured on the test
         # box: the DMA path has about 0.5 ms of fixed cost per copy but the higher rate, 21 against 17 GB/s)
         use_kernel = os.environ.get("RT_WB_COPY", "kernel" if rows * W * 3 < (12 << 20) else "memcpy") == "kernel"
-        d_buf = [part_u8] + [torch.empty_like(part_u8) for _ in range(n_buf - 1)]
+        d_buf = part_bufs
         h_buf = [torch.empty((rows, W, 3), dtype=torch.uint8, pin_memory=True) for _ in range(n_buf)]
-        ev_r = [torch.cuda.Event() for _ in range(n_buf)]
-        ev_c = [torch.cuda.Event() for _ in range(n_buf)]
         p_copy = rt.default_params(W, rows)                          # whole-buffer copy: one part, rows as they are
 
         def step_wb(k):
             b = k % n_buf
-            if k >= n_buf:
-                main_stream.wait_event(ev_c[b])                 # the copy of frame k - n_buf has left this device buffer
-            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=d_buf[b].data_ptr(), stream=stream)
-            ev_r[b].record(main_stream)
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ev_r[b])
-                if use_kernel:
-                    # pinned host memory is mapped into the device's address space: a copy kernel writes it over PCIe
-                    rt.deinterleave_device(p_copy, d_buf[b].data_ptr(), h_buf[b].data_ptr(), 3, stream=copy_stream.cuda_stream)
-                else:
+            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=d_buf[b].data_ptr(), stream=lane_handles[b])
+            if use_kernel:
+                # pinned host memory is mapped into the device's address space: a copy kernel writes it over PCIe
+                rt.deinterleave_device(p_copy, d_buf[b].data_ptr(), h_buf[b].data_ptr(), 3, stream=lane_handles[b])
+            else:
+                with torch.cuda.stream(lanes[b]):
                     h_buf[b].copy_(d_buf[b], non_blocking=True)
-                ev_c[b].record(copy_stream)
 
         for k in range(max(args.warmup, n_buf)):
             step_wb(k)
@@ -299,22 +307,26 @@ def main():
         last = (args.steps - 1) % n_buf
         wb = {"ms": round(dt_wb * 1e3, 4), "bytes_equal": bool(torch.equal(h_buf[last], d_buf[last].cpu())),
               "mrays": round(rays_local / dt_wb / 1e6, 2), "bytes_per_frame": int(h_buf[0].numel()),
-              "how": "%d device + %d pinned host buffers, %s on a copy stream beside the next frames" % (n_buf, n_buf, "copy kernel writing the mapped host buffer" if use_kernel else "hipMemcpyAsync")}
+              "how": "%d lanes, each with a device and a pinned host buffer; %s behind the trace on the frame's lane, beside the other lanes' frames" % (n_buf, "copy kernel writing the mapped host buffer" if use_kernel else "hipMemcpyAsync")}
 
     # Traversal stress beside the headline: same scene, close camera (untimed by the driver; a few frames)
     stress = None
     if world == 1 and not args.no_extras and args.workload in ("nefertiti4k", "nefertiti8k") and "cam_pos" not in pkw:
         ps = rt.default_params(W, H, walk_mode=walk, **STRESS_CAMERA)
         n_s = max(3, min(args.steps, 10))
-        for _ in range(2):
-            scene.render_device(ps, rebuild_grid=not args.no_rebuild, d_u8=part_u8.data_ptr(), stream=stream)
+        for k in range(n_lanes):
+            scene.render_device(ps, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[k].data_ptr(), stream=lane_handles[k])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n_s):
-            scene.render_device(ps, rebuild_grid=not args.no_rebuild, d_u8=part_u8.data_ptr(), stream=stream)
+        for k in range(n_s):
+            scene.render_device(ps, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[k % n_lanes].data_ptr(), stream=lane_handles[k % n_lanes])
         torch.cuda.synchronize()
         dt_s = (time.perf_counter() - t0) / n_s
-        st_s = [scene.stats_at(i) for i in range(n_s)]
+        # kernel times of this frame alone on the GPU: a few frames one after the other on one lane
+        for _ in range(4):
+            scene.render_device(ps, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
+        torch.cuda.synchronize()
+        st_s = [scene.stats_at(i) for i in range(3)]
         ms_r = float(np.mean([x["ms_render"] for x in st_s])); ms_b = float(np.mean([x["ms_build"] for x in st_s]))
         scene.set_counting(True)
         scene.render_device(ps, rebuild_grid=False, d_u8=part_u8.data_ptr(), stream=stream)
@@ -326,8 +338,8 @@ def main():
         f64s = c2["tests_executed"] * FLOP_TEST_F64 + nr * FLOP_RAY_F64
         stress = {"workload": "same scene, camera %s -> %s (%.0f %% of the primary rays enter the grid, %.0f %% hit)" % (
                       STRESS_CAMERA["cam_pos"], STRESS_CAMERA["cam_target"], 100.0 * c2["primary_entering"] / c2["primary_rays"], 100.0 * c2["hits"] / c2["primary_rays"]),
-                  "value": round(nr / dt_s / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(dt_s * 1e3, 4), "frames": n_s,
-                  "frame_ms": {"build": round(ms_b, 4), "render": round(ms_r, 4)},
+                  "value": round(nr / dt_s / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(dt_s * 1e3, 4), "frames": n_s, "frames_in_flight": n_lanes,
+                  "frame_ms_alone": {"build": round(ms_b, 4), "render": round(ms_r, 4)},
                   "ns_per_entering_ray": round(ms_r * 1e6 / max(c2["primary_entering"] + c2["shadow_entering"], 1), 3),
                   "rays": int(nr), "entering": int(c2["primary_entering"] + c2["shadow_entering"]), "tests_executed": int(c2["tests_executed"]),
                   "roofline_frac": round((f32s / PEAK_FP32 + f64s / PEAK_FP64) / (ms_r * 1e-3), 5)}
@@ -345,6 +357,7 @@ def main():
         f32 = tests * FLOP_TEST_F32 + steps_ * FLOP_STEP_F32 + nrays * FLOP_RAY_F32
         f64 = tests * FLOP_TEST_F64 + nrays * FLOP_RAY_F64
         t_render = ms_render * 1e-3
+        t_render_alone = ms_render_alone * 1e-3
         t_peak = f32 / PEAK_FP32 + f64 / PEAK_FP64
         # compulsory HBM traffic of the render kernel: records 48 B/ref, cell table, RGB8 framebuffer
         hbm_bytes = cs["n_refs"] * 48 + (cs["n_cells"] + 1) * 4 + cs["n_cells"] / 8 + cs["primary_rays"] * 3
@@ -369,22 +382,33 @@ def main():
             "dtype": "f32+f64",
             "data": "synthetic" if "STAND-IN" in label or "plane" in label else "reference meshes",
             "config": {"workload": label, "walk": args.walk, "rays_per_frame": int(rays_total), "hits": int(hits_total),
-                       "frame": "grid build + render + RGB8 framebuffer" + (" + RCCL gather + de-interleave (on their own stream, beside the next frame's build)" if world > 1 else ""),
+                       "frame": "grid build + render + RGB8 framebuffer" + (" + RCCL gather + de-interleave" if world > 1 else ""),
+                       "frames_in_flight": n_lanes,
+                       "pipeline": ("frame k runs on stream k %% %d with its own working set and output buffers; every frame builds its own grid; "
+                                    "value = frames completed / wall time" % n_lanes) if n_lanes > 1 else "one frame at a time on one stream",
                        "partition": "interleaved 8-row bands, scene replicated" if world > 1 else "single GPU",
                        "triangles": cs["n_triangles"], "grid": cs["grid_n"], "cell_refs": cs["n_refs"]},
             "frame_ms": {"build": round(ms_build, 4), "render": round(ms_render, 4), "device_total": round(ms_build + ms_render, 4),
+                         "note": "first build kernel to the start of the trace kernel, trace kernel, and their sum (the latency of a frame), "
+                                 "as the frames of the timed region saw them, i.e. sharing the GPU with %d other frames" % (n_lanes - 1) if n_lanes > 1 else
+                                 "first build kernel to the start of the trace kernel, trace kernel, their sum",
+                         "alone": {"build": round(ms_build_alone, 4), "render": round(ms_render_alone, 4), "device_total": round(ms_build_alone + ms_render_alone, 4)},
                          "with_host_writeback": wb["ms"] if wb else None},
             "host_writeback": wb,
             "stress": stress,
-            "render_only_mrays": round(rays_local / t_render / 1e6, 2) if t_render > 0 else None,
+            "render_only_mrays": round(rays_local / t_render_alone / 1e6, 2) if t_render_alone > 0 else None,
             "roofline": {
                 "bound": "valu", "kernel": "k_trace",
                 "achieved": round((f32 + f64) / t_render / 1e12, 4), "peak": round((f32 + f64) / t_peak / 1e12, 2), "unit": "TFLOP/s",
                 "frac": round(t_peak / t_render, 5),
+                "alone": {"achieved": round((f32 + f64) / t_render_alone / 1e12, 4), "frac": round(t_peak / t_render_alone, 5), "ms": round(ms_render_alone, 4),
+                          "note": "the same launch with the GPU to itself (frames one after the other on one stream, after the timed region)"},
+                "per_frame": {"achieved": round((f32 + f64) / (ms_per_step * 1e-3) / 1e12, 4), "frac": round(t_peak / (ms_per_step * 1e-3), 5),
+                              "note": "the same flops over the wall time per frame of the timed region (build and everything else included): what the pipeline as a whole achieves"},
                 "traffic": traffic,
                 "traffic_note": "HBM-side bytes of one k_trace launch from the L2 fabric counters (profiles/traffic.json: separate rocprofv3 --pmc passes, FETCH_SIZE doubled on gfx950)",
                 "note": "flops of the triangle tests k_trace executes (%d; the reference's early-exit order needs %d, the rest are skipped by the per-run "
-                        "box test), %d voxel steps and %d rays of rank 0's frame, over the mean k_trace time of the timed frames (hipEvents around the launch, recorded by the library on its stream); "
+                        "box test), %d voxel steps and %d rays of rank 0's frame, over the mean k_trace time of the timed frames (100 MHz clock values written at the kernel's start and end; with frames in flight the launch shares the GPU with other frames' kernels, which stretches it); "
                         "peak = the same flops at 157.3 TF fp32 + 78.6 TF fp64" % (tests, tests_ref, steps_, nrays),
             },
             "roofline_hbm": {

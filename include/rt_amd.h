@@ -148,6 +148,22 @@ int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_grid, void* d_
  * in time on one GPU (two streams, two threads) race; calls on one stream, or ordered by the caller, are safe, also for
  * different scenes. No frame statistics are recorded for these frames. */
 int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id, void* stream);
+/* ---- several frames in flight (no counterpart in the reference, which renders one frame and exits) ----
+ * A frame is a chain of about a dozen kernels (grid build, tile lists, trace) of which the first ones are short and narrow
+ * and the last one ends in a tail of a few long wavefronts: one frame at a time leaves a good part of the GPU idle. With n
+ * working sets (grid tables, reference lists, work lists; the triangles are shared) a scene keeps up to n frames in flight:
+ * rt_render_device() calls on different streams use different sets and overlap on the GPU, calls on one stream share a set
+ * and are ordered by the stream as before. Default 1 (the call also waits for the device and forgets which stream used
+ * which set). A stream handed to a scene has to stay valid until the scene is destroyed or this call is made again.
+ * Output buffers belong to the caller: frames in flight need one each. */
+int rt_scene_set_frames_in_flight(rt_scene* s, int32_t n);        /* 1..8 */
+int32_t rt_scene_frames_in_flight(const rt_scene* s);
+/* Up to n streams (hipStream_t, non-blocking) that really run side by side: the HIP runtime maps the streams of a process
+ * onto a few hardware queues (four by default), and two streams on one queue execute in order. Each stream returned has
+ * been checked, with a short kernel, to overlap with every other one. Returns how many were found (at least 1, at most n)
+ * or a negative rt_status. */
+int32_t rt_streams_create(int32_t n, void** streams);
+int rt_streams_destroy(int32_t n, void* const* streams);
 /* Host-buffer variant (uploads if needed, renders, copies back, synchronises). Buffers may be NULL. */
 int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id);
 /* render() including its file output: writes "P6\nW H\n255\n" + body to `path` ("./test.ppm" in the reference). */

@@ -82,7 +82,7 @@ EXPORTS = [
     "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_add_obj_material", "rt_scene_add_triangles_material", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
-    "rt_render_device", "rt_render_device_noalloc", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_unit_costs",
+    "rt_render_device", "rt_render_device_noalloc", "rt_scene_set_frames_in_flight", "rt_scene_frames_in_flight", "rt_streams_create", "rt_streams_destroy", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_unit_costs",
     "rt_deinterleave_device", "rt_selftest_division", "rt_comm_create", "rt_comm_destroy", "rt_comm_size", "rt_gather_bands",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
@@ -138,6 +138,12 @@ def lib():
     L.rt_scene_record_order.argtypes = [vp, vp, vp]
     L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
     L.rt_render_device_noalloc.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.rt_scene_set_frames_in_flight.argtypes = [vp, i32]
+    L.rt_scene_frames_in_flight.argtypes = [vp]
+    L.rt_scene_frames_in_flight.restype = i32
+    L.rt_streams_create.argtypes = [i32, vp]
+    L.rt_streams_create.restype = i32
+    L.rt_streams_destroy.argtypes = [i32, vp]
     L.rt_deinterleave_device.argtypes = [vp, vp, vp, i32, vp]
     L.rt_comm_create.argtypes = [i32, vp, C.POINTER(vp)]
     L.rt_comm_destroy.argtypes = [vp]
@@ -276,6 +282,13 @@ class Scene:
         """rt_render_device_noalloc: the frame's working memory is the library's fixed device array."""
         _check(lib().rt_render_device_noalloc(self.h, C.byref(params), d_rgb, d_u8, d_ids, stream))
 
+    def set_frames_in_flight(self, n):
+        """Working sets of the scene: frames on up to n different streams overlap on the GPU (rt_scene_set_frames_in_flight)."""
+        _check(lib().rt_scene_set_frames_in_flight(self.h, n))
+
+    def frames_in_flight(self):
+        return lib().rt_scene_frames_in_flight(self.h)
+
     def record_order(self):
         """(area unsorted, area sorted, frames sort?) as measured by upload(); see rt_scene_record_order."""
         a, srt = (C.c_double * 2)(), C.c_int32()
@@ -289,6 +302,19 @@ class Scene:
 
     def set_counting(self, enable):
         _check(lib().rt_scene_set_counting(self.h, int(bool(enable))))
+
+
+def create_streams(n):
+    """Up to n stream handles (integers) that run side by side on the GPU, see rt_streams_create; release them with
+    destroy_streams(). torch.cuda.ExternalStream(handle) makes one usable from torch."""
+    arr = (C.c_void_p * n)()
+    k = _check(lib().rt_streams_create(n, arr))
+    return [int(arr[i]) for i in range(k)]
+
+
+def destroy_streams(handles):
+    arr = (C.c_void_p * len(handles))(*handles)
+    _check(lib().rt_streams_destroy(len(handles), arr))
 
 
 def part_row_map(params):

@@ -70,6 +70,40 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Working memory of one frame in flight: everything the grid build and the render kernels write besides the caller's
+// outputs, with the state of the grid it holds and the stream its last frame ran on. A scene has one of these unless
+// rt_scene_set_frames_in_flight() asks for more; frames on different streams then use different sets and may overlap on
+// the GPU, frames on one stream share a set and are ordered by the stream.
+#define RT_MAX_IN_FLIGHT 8
+struct WorkSet {
+    DevBuf<RtGrid> d_grid;
+    DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
+    DevBuf<uint2> row_minmax;
+    DevBuf<float4> recs, blk_bounds;
+    DevBuf<unsigned long long> counters;   // 24 frame counters, the work-list words (RtRenderWork::work, 32 of them), 32 partial sums of the cost estimate
+    DevBuf<uint32_t> tile_list, unit_cost, tile_cost, queue_lists;
+    bool zeroed = false;               // the fixed-size tables exist and were cleared for the current triangle list
+    bool grid_valid = false;
+    bool build_clean = false;          // the last grid build ran to its end and left its counters reset for the next one
+    bool grid_sorted = false;          // how the current grid was built
+    hipStream_t last_stream = nullptr; // stream of the last frame or grid build on this set
+    bool stream_used = false;
+    uint64_t last_ticket = 0;          // when it was last used, to find the set that has been idle longest
+    hipStream_t side_stream = nullptr; // work-list preparation beside the grid build (created when first needed)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void release() {
+        d_grid.release(); bounds_enc.release(); cell_count.release(); cell_start.release(); block_sums.release(); occupancy.release();
+        ref_tri.release(); ref_cell.release(); row_minmax.release(); recs.release(); blk_bounds.release(); counters.release();
+        tile_list.release(); unit_cost.release(); tile_cost.release(); queue_lists.release();
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        ev_fork = ev_join = nullptr; side_stream = nullptr;
+        zeroed = grid_valid = build_clean = grid_sorted = stream_used = false;
+        last_stream = nullptr;
+    }
+};
+
 struct rt_scene {
     // host triangle list: what load_mesh() builds, flattened
     std::vector<float> tri;            // 9 floats per triangle: v0 v1 v2
@@ -79,19 +113,15 @@ struct rt_scene {
     // device state
     int device = -1;
     bool uploaded = false;
-    bool grid_valid = false;
     uint32_t known_refs = 0;           // reference count of the current triangle list once measured
     bool refs_known = false;
-    bool build_clean = false;          // the last grid build ran to its end and left its counters reset for the next one
     DevBuf<float4> v0, v1, v2, tri_rec;
     DevBuf<float2> tri_box;
     DevBuf<float> d_mesh_color, d_mesh_mat;
-    DevBuf<RtGrid> d_grid;
-    DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
-    DevBuf<uint2> row_minmax;
-    DevBuf<float4> recs, blk_bounds;
-    DevBuf<unsigned long long> counters;   // 24 frame counters, the work-list words (RtRenderWork::work, 32 of them), 32 partial sums of the cost estimate
-    DevBuf<uint32_t> tile_list, unit_cost, tile_cost, queue_lists;
+    WorkSet sets[RT_MAX_IN_FLIGHT];
+    int n_sets = 1;                    // rt_scene_set_frames_in_flight()
+    int cur = 0;                       // set of the last frame or grid build: what the read-backs and the statistics look at
+    uint64_t ticket = 0;
     int n_cu = 0;
     uint32_t known_cells = 0;              // n_cells of the current triangle list once measured
     RtGrid h_grid;                         // grid description of the current triangle list once measured
@@ -112,10 +142,7 @@ struct rt_scene {
     uint64_t sched_shifts = 0x2222000011112222ull;
     bool sched_adapt = true;               // off when RT_SHIFTS gives the unit sizes explicitly
     float est_w[4] = {1.f, 500.f, 0.f, 700.f};    // cost estimate weights: primary triangles, primary voxels, shadow triangles, shadow voxels
-    hipStream_t last_stream = nullptr;       // stream of the last frame or grid build (build state is shared between frames)
-    bool stream_used = false;
-    hipStream_t side_stream = nullptr;       // work-list preparation beside the grid build
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int side_stream_override = -1;           // RT_SIDE_STREAM: 0 / 1, -1 = the library decides
     rt_params last_params;
     // experiment overrides, read once when the scene is created: RT_OWN_PATH (-1 = the library decides), RT_CULL_MIN
     // (1..65535), RT_CULL_LANE_RUNS (0..64), RT_BLOCKS_PER_CU (0 = no cap)
@@ -129,7 +156,6 @@ struct rt_scene {
     int force_sorted = -1;                   // RT_SORTED_BUILD: 0 / 1 force a build mode, -1 = the library decides
     bool prefer_sorted = false;              // measured once per triangle list (scene_choose_record_order)
     double run_area[2] = {0, 0};             // what was measured: summed run-box areas, unsorted and sorted
-    bool grid_sorted = false;                // how the current grid was built
     bool want_sorted() const { return count_work || (force_sorted >= 0 ? force_sorted != 0 : prefer_sorted); }
 };
 
@@ -161,6 +187,7 @@ extern "C" rt_scene* rt_scene_create(void) {
         s->cull_lane_runs = env_int("RT_CULL_LANE_RUNS", 0, 64, 12);
         s->blocks_per_cu_cap = env_int("RT_BLOCKS_PER_CU", 1, 64, 0);
         s->force_sorted = env_int("RT_SORTED_BUILD", 0, 1, -1);
+        s->side_stream_override = env_int("RT_SIDE_STREAM", 0, 1, -1);
     }
     return s;
 }
@@ -169,19 +196,18 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     if (s->device >= 0) {
         (void)hipSetDevice(s->device);
-        s->v0.release(); s->v1.release(); s->v2.release(); s->tri_rec.release(); s->tri_box.release(); s->d_mesh_color.release(); s->d_mesh_mat.release(); s->d_grid.release();
-        s->bounds_enc.release(); s->cell_count.release(); s->cell_start.release(); s->block_sums.release();
-        s->occupancy.release(); s->ref_tri.release(); s->ref_cell.release(); s->row_minmax.release(); s->recs.release(); s->blk_bounds.release(); s->counters.release(); s->tile_list.release(); s->unit_cost.release(); s->tile_cost.release(); s->queue_lists.release();
+        s->v0.release(); s->v1.release(); s->v2.release(); s->tri_rec.release(); s->tri_box.release(); s->d_mesh_color.release(); s->d_mesh_mat.release();
+        for (WorkSet& w : s->sets) w.release();
         s->o_rgb.release(); s->o_u8.release(); s->o_id.release();
         s->stamps.release();
-        if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-        if (s->ev_join) (void)hipEventDestroy(s->ev_join);
-        if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
     }
     delete s;
 }
 
-static void scene_touch(rt_scene* s) { s->uploaded = false; s->grid_valid = false; s->refs_known = false; s->build_clean = false; }
+static void scene_touch(rt_scene* s) {
+    s->uploaded = false; s->refs_known = false;
+    for (WorkSet& w : s->sets) { w.grid_valid = false; w.build_clean = false; }
+}
 
 // entry 1 of the Parallel tree's material table (Parallel/raytracer.cu:451) around a given colour
 static rt_material default_material(const float color[3]) {
@@ -400,16 +426,12 @@ static int scene_bind_device(rt_scene* s) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         s->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
     }
     return RT_OK;
 }
 
-// Working memory of a frame: everything the grid build and the render kernels write besides the caller's outputs.
-// A scene owns one set (allocated on demand, reused by later frames); rt_render_device_noalloc() uses a set carved out
-// of a fixed device array instead.
+// Working memory of a frame as the frame code sees it: plain pointers, either into a WorkSet of the scene (allocated on
+// demand, reused by later frames) or, for rt_render_device_noalloc(), into a fixed device array.
 struct FrameMem {
     RtGrid* grid = nullptr;
     uint32_t *bounds_enc = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr, *occupancy = nullptr;
@@ -425,17 +447,36 @@ struct FrameMem {
 };
 #define RT_COUNTER_WORDS 88                  // 24 frame counters, 32 work-list words (64 x u32), 32 partial sums of the cost estimate
 
-static FrameMem scene_mem(rt_scene* s) {
+static FrameMem scene_mem(const rt_scene* s, const WorkSet& w) {
     FrameMem m;
-    m.grid = s->d_grid.p; m.bounds_enc = s->bounds_enc.p; m.cell_count = s->cell_count.p; m.cell_start = s->cell_start.p;
-    m.block_sums = s->block_sums.p; m.occupancy = s->occupancy.p;
-    m.ref_tri = s->ref_tri.p; m.ref_cell = s->ref_cell.p; m.row_minmax = s->row_minmax.p; m.recs = s->recs.p; m.blk_bounds = s->blk_bounds.p;
-    m.ref_cap = s->recs.cap / 3;
+    m.grid = w.d_grid.p; m.bounds_enc = w.bounds_enc.p; m.cell_count = w.cell_count.p; m.cell_start = w.cell_start.p;
+    m.block_sums = w.block_sums.p; m.occupancy = w.occupancy.p;
+    m.ref_tri = w.ref_tri.p; m.ref_cell = w.ref_cell.p; m.row_minmax = w.row_minmax.p; m.recs = w.recs.p; m.blk_bounds = w.blk_bounds.p;
+    m.ref_cap = w.recs.cap / 3;
     m.sorted = s->want_sorted();
-    m.counters = s->counters.p;
-    m.tile_list = s->tile_list.p; m.tile_cost = s->tile_cost.p; m.queue_lists = s->queue_lists.p; m.tile_cap = s->tile_list.cap;
-    m.unit_cost = s->unit_cost.p;
+    m.counters = w.counters.p;
+    m.tile_list = w.tile_list.p; m.tile_cost = w.tile_cost.p; m.queue_lists = w.queue_lists.p; m.tile_cap = w.tile_list.cap;
+    m.unit_cost = w.unit_cost.p;
     return m;
+}
+
+// The fixed-size tables of a set, cleared once per triangle list (an empty scene never builds a grid and reads them as
+// they are).
+static int workset_prepare(WorkSet& w) {
+    if (w.zeroed) return RT_OK;
+    int rc;
+    if ((rc = w.d_grid.ensure(1)) || (rc = w.bounds_enc.ensure(8)) || (rc = w.cell_count.ensure(RT_MAX_CELLS)) ||
+        (rc = w.cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = w.block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
+        (rc = w.occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = w.counters.ensure(RT_COUNTER_WORDS)))
+        return rc;
+    HIP_TRY(hipMemset(w.d_grid.p, 0, sizeof(RtGrid)));
+    HIP_TRY(hipMemset(w.cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(w.occupancy.p, 0, (RT_MAX_CELLS / 32 + 2) * sizeof(uint32_t)));
+    HIP_TRY(hipStreamSynchronize(nullptr));       // the frames run on other streams than these memsets
+    w.zeroed = true;
+    w.grid_valid = false;
+    w.build_clean = false;
+    return RT_OK;
 }
 
 static RtBuildDev build_args(rt_scene* s, const FrameMem& m) {
@@ -454,17 +495,39 @@ static RtBuildDev build_args(rt_scene* s, const FrameMem& m) {
     return b;
 }
 
-// The scene's build state (counters the build kernels leave reset, the work list, the fork/join events) is shared between
-// frames, so consecutive frames and grid builds of one scene have to be ordered. On one stream they are. When the caller
-// switches streams the host waits for the work enqueued on the old one (a rare case; an event per frame just to be able
-// to order streams on the device would cost every frame about 6 us of idle GPU).
-static int scene_enter_stream(rt_scene* s, hipStream_t st) {
-    if (s->stream_used && st != s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
+// The build state of a working set (counters the build kernels leave reset, the work list, the fork/join events) is shared
+// between the frames that use it, so those frames have to be ordered. On one stream they are: a frame takes the set its
+// stream used last. A stream the scene has not seen takes a set that is still free, and once all are taken the one that
+// has been idle longest, after the host has waited for the work enqueued on that set's old stream (a rare case; an event
+// per frame just to be able to order streams on the device would cost every frame about 6 us of idle GPU). With one set
+// this is: frames on one stream are ordered by it, a change of stream waits.
+static int scene_enter_stream(rt_scene* s, hipStream_t st, WorkSet** out) {
+    int pick = -1;
+    for (int i = 0; i < s->n_sets && pick < 0; ++i)
+        if (s->sets[i].stream_used && s->sets[i].last_stream == st) pick = i;
+    for (int i = 0; i < s->n_sets && pick < 0; ++i)
+        if (!s->sets[i].stream_used) pick = i;
+    if (pick < 0) {
+        pick = 0;
+        for (int i = 1; i < s->n_sets; ++i)
+            if (s->sets[i].last_ticket < s->sets[pick].last_ticket) pick = i;
+        HIP_TRY(hipStreamSynchronize(s->sets[pick].last_stream));
+    }
+    int rc = workset_prepare(s->sets[pick]);
+    if (rc) return rc;
+    *out = &s->sets[pick];
     return RT_OK;
 }
-static int scene_leave_stream(rt_scene* s, hipStream_t st) {
-    s->last_stream = st;
-    s->stream_used = true;
+static int scene_leave_stream(rt_scene* s, WorkSet* w, hipStream_t st) {
+    w->last_stream = st;
+    w->stream_used = true;
+    w->last_ticket = ++s->ticket;
+    s->cur = (int)(w - s->sets);
+    return RT_OK;
+}
+static int scene_sync_streams(rt_scene* s) {
+    for (int i = 0; i < s->n_sets; ++i)
+        if (s->sets[i].stream_used) HIP_TRY(hipStreamSynchronize(s->sets[i].last_stream));
     return RT_OK;
 }
 
@@ -472,15 +535,16 @@ static int scene_leave_stream(rt_scene* s, hipStream_t st) {
 // triangle list has and what its grid looks like. Known before any frame, so that frames never wait for the device.
 static int scene_measure_grid(rt_scene* s) {
     if (s->refs_known) return RT_OK;
-    HIP_TRY(rt_launch_build_phase1(build_args(s, scene_mem(s)), true, nullptr));
+    WorkSet& w = s->sets[0];
+    HIP_TRY(rt_launch_build_phase1(build_args(s, scene_mem(s, w)), true, nullptr));
     RtGrid g;
-    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&g, w.d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
     s->known_refs = g.n_refs;
     s->known_cells = (uint32_t)g.n_cells;
     s->h_grid = g;
     s->refs_known = true;
-    s->build_clean = false;      // the count was not consumed by a scatter
-    s->grid_valid = false;
+    w.build_clean = false;      // the count was not consumed by a scatter
+    w.grid_valid = false;
     return RT_OK;
 }
 
@@ -499,15 +563,16 @@ static int scene_choose_record_order(rt_scene* s) {
     s->run_area[0] = s->run_area[1] = 0;
     if (s->force_sorted >= 0 || s->n_tris() <= 65536 || s->known_refs == 0) return RT_OK;      // small meshes: voxels too small for run culling
     int rc;
+    WorkSet& w = s->sets[0];
     const size_t need = s->known_refs;
-    if ((rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(3 * (need / 64 + 2))) || (rc = s->ref_tri.ensure(need)) ||
-        (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)))
+    if ((rc = w.recs.ensure(3 * need)) || (rc = w.blk_bounds.ensure(3 * (need / 64 + 2))) || (rc = w.ref_tri.ensure(need)) ||
+        (rc = w.ref_cell.ensure(need)) || (rc = w.row_minmax.ensure(need / 64 + 2)))
         return rc;
     DevBuf<double> d_area;
     if ((rc = d_area.ensure(2))) return rc;
     hipError_t e = hipMemset(d_area.p, 0, 2 * sizeof(double));
     for (int mode = 1; mode >= 0 && e == hipSuccess; --mode) {        // sorted first, so that the unsorted grid is the one left behind
-        FrameMem m = scene_mem(s);
+        FrameMem m = scene_mem(s, w);
         m.sorted = mode == 1;
         if (build_grid_async(s, m, true, nullptr, nullptr, nullptr)) { d_area.release(); return RT_ERR_HIP; }
         e = rt_launch_run_area(build_args(s, m), d_area.p + mode, nullptr);
@@ -516,9 +581,9 @@ static int scene_choose_record_order(rt_scene* s) {
     d_area.release();
     if (e != hipSuccess) return set_err(RT_ERR_HIP, "record order measurement: %s", hipGetErrorString(e));
     s->prefer_sorted = s->run_area[0] > 1.10 * s->run_area[1];
-    if (!s->prefer_sorted) { s->ref_tri.release(); s->ref_cell.release(); s->row_minmax.release(); }
-    s->grid_valid = false;
-    s->build_clean = false;
+    if (!s->prefer_sorted) { w.ref_tri.release(); w.ref_cell.release(); w.row_minmax.release(); }
+    w.grid_valid = false;
+    w.build_clean = false;
     return RT_OK;
 }
 
@@ -532,18 +597,13 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     if ((rc = s->v0.ensure(Tn)) || (rc = s->v1.ensure(Tn)) || (rc = s->v2.ensure(Tn)) || (rc = s->tri_rec.ensure(3 * Tn)) || (rc = s->tri_box.ensure(3 * Tn))) return rc;
     if ((rc = s->d_mesh_color.ensure(s->mesh_color.size() ? s->mesh_color.size() : 3))) return rc;
     if ((rc = s->d_mesh_mat.ensure(s->mesh_mat.size() ? s->mesh_mat.size() : 8))) return rc;
-    if ((rc = s->d_grid.ensure(1)) || (rc = s->bounds_enc.ensure(8)) || (rc = s->cell_count.ensure(RT_MAX_CELLS)) ||
-        (rc = s->cell_start.ensure(RT_MAX_CELLS + 1)) || (rc = s->block_sums.ensure(RT_MAX_SCAN_BLOCKS)) ||
-        (rc = s->occupancy.ensure(RT_MAX_CELLS / 32 + 2)) || (rc = s->counters.ensure(RT_COUNTER_WORDS)))
-        return rc;
     if (!s->stamps.p) {
         if ((rc = s->stamps.ensure(RT_STATS_RING * 4))) return rc;
         HIP_TRY(hipMemset(s->stamps.p, 0, RT_STATS_RING * 4 * sizeof(unsigned long long)));
     }
     HIP_TRY(hipDeviceSynchronize());         // frames of the previous triangle list may still be reading these buffers
-    HIP_TRY(hipMemset(s->d_grid.p, 0, sizeof(RtGrid)));
-    HIP_TRY(hipMemset(s->cell_start.p, 0, (RT_MAX_CELLS + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(s->occupancy.p, 0, (RT_MAX_CELLS / 32 + 2) * sizeof(uint32_t)));
+    for (WorkSet& w : s->sets) w.zeroed = false;
+    if ((rc = workset_prepare(s->sets[0]))) return rc;
     if (T) {
         // stage the 36-byte host records and the mesh indices, then split them into float4 streams on the device
         DevBuf<float> stage;
@@ -551,7 +611,7 @@ extern "C" int rt_scene_upload(rt_scene* s) {
         if ((rc = stage.ensure(9 * T)) || (rc = stage_mesh.ensure(T))) { stage.release(); stage_mesh.release(); return rc; }
         hipError_t e = hipMemcpy(stage.p, s->tri.data(), 9 * T * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(stage_mesh.p, s->tri_mesh.data(), T * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = rt_launch_upload_convert(stage.p, stage_mesh.p, build_args(s, scene_mem(s)), nullptr);
+        if (e == hipSuccess) e = rt_launch_upload_convert(stage.p, stage_mesh.p, build_args(s, scene_mem(s, s->sets[0])), nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         stage.release(); stage_mesh.release();
         if (e != hipSuccess) return set_err(RT_ERR_HIP, "scene upload: %s", hipGetErrorString(e));
@@ -561,8 +621,6 @@ extern "C" int rt_scene_upload(rt_scene* s) {
         HIP_TRY(hipMemcpy(s->d_mesh_mat.p, s->mesh_mat.data(), s->mesh_mat.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     s->uploaded = true;
-    s->grid_valid = false;
-    s->build_clean = false;
     s->refs_known = false;
     if ((rc = scene_measure_grid(s))) return rc;
     return scene_choose_record_order(s);
@@ -582,23 +640,23 @@ static int build_grid_async(rt_scene* s, const FrameMem& m, bool first, hipStrea
 }
 
 // The scene's own reference arrays, sized from the measured reference count.
-static int scene_ensure_refs(rt_scene* s) {
+static int scene_ensure_refs(rt_scene* s, WorkSet& w) {
     int rc;
     const size_t need = s->known_refs ? s->known_refs : 1;
-    if ((rc = s->recs.ensure(3 * need)) || (rc = s->blk_bounds.ensure(3 * (need / 64 + 2)))) return rc;
-    if (s->want_sorted() && ((rc = s->ref_tri.ensure(need)) || (rc = s->ref_cell.ensure(need)) || (rc = s->row_minmax.ensure(need / 64 + 2)))) return rc;
+    if ((rc = w.recs.ensure(3 * need)) || (rc = w.blk_bounds.ensure(3 * (need / 64 + 2)))) return rc;
+    if (s->want_sorted() && ((rc = w.ref_tri.ensure(need)) || (rc = w.ref_cell.ensure(need)) || (rc = w.row_minmax.ensure(need / 64 + 2)))) return rc;
     return RT_OK;
 }
 
-static int scene_build_grid_async(rt_scene* s, hipStream_t st, hipEvent_t after_phase1 = nullptr) {
-    int rc = scene_ensure_refs(s);
+static int scene_build_grid_async(rt_scene* s, WorkSet& w, hipStream_t st) {
+    int rc = scene_ensure_refs(s, w);
     if (rc) return rc;
-    const bool first = !s->build_clean;
-    s->build_clean = false;
-    if ((rc = build_grid_async(s, scene_mem(s), first, st, after_phase1, nullptr))) return rc;
-    s->grid_valid = true;
-    s->build_clean = true;
-    s->grid_sorted = s->want_sorted();
+    const bool first = !w.build_clean;
+    w.build_clean = false;
+    if ((rc = build_grid_async(s, scene_mem(s, w), first, st, nullptr, nullptr))) return rc;
+    w.grid_valid = true;
+    w.build_clean = true;
+    w.grid_sorted = s->want_sorted();
     return RT_OK;
 }
 
@@ -607,16 +665,17 @@ extern "C" int rt_scene_build_grid(rt_scene* s, void* stream) {
     int rc = rt_scene_upload(s);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = scene_enter_stream(s, st))) return rc;
-    if ((rc = scene_build_grid_async(s, st))) return rc;
-    return scene_leave_stream(s, st);
+    WorkSet* w = nullptr;
+    if ((rc = scene_enter_stream(s, st, &w))) return rc;
+    if ((rc = scene_build_grid_async(s, *w, st))) return rc;
+    return scene_leave_stream(s, w, st);
 }
 
 extern "C" int rt_scene_get_grid(rt_scene* s, int32_t n[3], float lohi[6], float width[3], float inv_width[3], uint32_t* n_cells, uint32_t* n_refs) {
-    if (!s || !s->grid_valid) return set_err(RT_ERR_INVALID, "rt_scene_get_grid: grid not built");
+    if (!s || !s->sets[s->cur].grid_valid) return set_err(RT_ERR_INVALID, "rt_scene_get_grid: grid not built");
     HIP_TRY(hipDeviceSynchronize());
     RtGrid g;
-    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&g, s->sets[s->cur].d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
     if (g.overflow) return set_err(RT_ERR_HIP, "grid reference capacity exceeded");
     for (int a = 0; a < 3; ++a) {
         if (n) n[a] = g.n[a];
@@ -630,25 +689,26 @@ extern "C" int rt_scene_get_grid(rt_scene* s, int32_t n[3], float lohi[6], float
 }
 
 extern "C" int rt_scene_get_csr(rt_scene* s, uint32_t* cell_start, uint32_t* cell_tris) {
-    if (!s || !s->grid_valid) return set_err(RT_ERR_INVALID, "rt_scene_get_csr: grid not built");
+    if (!s || !s->sets[s->cur].grid_valid) return set_err(RT_ERR_INVALID, "rt_scene_get_csr: grid not built");
     HIP_TRY(hipDeviceSynchronize());
-    if (!s->grid_sorted) {
+    WorkSet& w = s->sets[s->cur];
+    if (!w.grid_sorted) {
         // the lists are read back in the reference's order: build them that way once more
         const int forced = s->force_sorted;
         s->force_sorted = 1;
-        int rc = scene_build_grid_async(s, nullptr);
+        int rc = scene_build_grid_async(s, w, nullptr);
         s->force_sorted = forced;
         if (rc) return rc;
         HIP_TRY(hipDeviceSynchronize());      // (a later frame rebuilds in its own mode if that differs)
     }
     RtGrid g;
-    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
-    if (cell_start) HIP_TRY(hipMemcpy(cell_start, s->cell_start.p, ((size_t)g.n_cells + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&g, w.d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    if (cell_start) HIP_TRY(hipMemcpy(cell_start, w.cell_start.p, ((size_t)g.n_cells + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (cell_tris && g.n_refs) {
         DevBuf<uint32_t> tmp;
         int rc = tmp.ensure(g.n_refs);
         if (rc) return rc;
-        hipError_t e = rt_launch_extract_cell_tris(s->recs.p, tmp.p, g.n_refs, nullptr);
+        hipError_t e = rt_launch_extract_cell_tris(w.recs.p, tmp.p, g.n_refs, nullptr);
         if (e == hipSuccess) e = hipMemcpy(cell_tris, tmp.p, (size_t)g.n_refs * sizeof(uint32_t), hipMemcpyDeviceToHost);
         tmp.release();
         if (e != hipSuccess) return set_err(RT_ERR_HIP, "csr read-back: %s", hipGetErrorString(e));
@@ -713,24 +773,32 @@ static size_t frame_tiles(const rt_params* p) {
 }
 
 // One frame on the working memory `m`: clears the outputs, builds the grid when asked to, prepares the work list and
-// traces. `fork`: the scene's side stream and events may be used; without it everything is enqueued on `st` in order and
-// nothing but kernels and memsets is issued.
+// traces. `ws`: the working set `m` points into, whose side stream and events may be used; without it (NULL) everything is
+// enqueued on `st` in order and nothing but kernels and memsets is issued.
 // `build`: 0 = the grid in `m` is current, 1 = rebuild, the build state in `m` was left clean, 2 = rebuild from scratch.
 // `stamps` (may be NULL): four device words the kernels write the frame's times into, see rt_scene::stamps.
-static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int build, bool fork, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id,
+static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int build, WorkSet* ws, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id,
                         hipStream_t st, unsigned long long* stamps, bool* start_is_trace) {
     int rc;
     // Large meshes with a grid build in the frame: everything that only needs the grid's cell table (clearing the outputs,
     // the tile list and its cost classes, about 0.14 ms at 4K) runs on a side stream beside the second half of the build and
     // joins before the trace kernel. The fork and the join cost about 6 us and 12 us of idle stream each, which is more
     // than small meshes (up to 65,536 triangles: the whole preparation takes 45 us) would gain: they stay on one stream.
-    const bool use_side = fork && build != 0 && s->n_tris() > 65536;
+    // With several frames in flight the other frames fill what a build leaves idle, and the second stream would only compete
+    // with them for the few hardware queues.
+    bool use_side = ws && build != 0 && s->n_tris() > 65536 && s->n_sets == 1;
+    if (ws && build != 0 && s->side_stream_override >= 0) use_side = s->side_stream_override != 0;
     hipStream_t side = st;
+    if (use_side && !ws->side_stream) {
+        HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&ws->side_stream, hipStreamNonBlocking));
+    }
     if (build != 0) {
-        if ((rc = build_grid_async(s, m, build == 2, st, use_side ? s->ev_fork : nullptr, stamps))) return rc;
+        if ((rc = build_grid_async(s, m, build == 2, st, use_side ? ws->ev_fork : nullptr, stamps))) return rc;
         if (use_side) {
-            side = s->side_stream;
-            HIP_TRY(hipStreamWaitEvent(side, s->ev_fork, 0));
+            side = ws->side_stream;
+            HIP_TRY(hipStreamWaitEvent(side, ws->ev_fork, 0));
         }
     }
     const bool counting = s->count_work && m.unit_cost;
@@ -821,8 +889,8 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
     if (start_is_trace) *start_is_trace = build == 0 && !prep_runs;
     HIP_TRY(rt_launch_render_prep(sd, cam, sh, f, wk, side));
     if (side != st) {
-        HIP_TRY(hipEventRecord(s->ev_join, side));
-        HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
+        HIP_TRY(hipEventRecord(ws->ev_join, side));
+        HIP_TRY(hipStreamWaitEvent(st, ws->ev_join, 0));
     }
     HIP_TRY(rt_launch_trace(sd, cam, sh, f, o, wk, st));
     return RT_OK;
@@ -834,22 +902,23 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     if (rc) return rc;
     if ((rc = rt_scene_upload(s))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = scene_enter_stream(s, st))) return rc;
-    const bool rebuild = rebuild_grid || !s->grid_valid || s->grid_sorted != s->want_sorted();
+    WorkSet* w = nullptr;
+    if ((rc = scene_enter_stream(s, st, &w))) return rc;
+    const bool rebuild = rebuild_grid || !w->grid_valid || w->grid_sorted != s->want_sorted();
     // working memory of the frame, grown when the triangle list or the frame size has grown
     const size_t tiles = frame_tiles(p);
-    if ((rc = s->tile_list.ensure(tiles)) || (rc = s->tile_cost.ensure(tiles)) || (rc = s->queue_lists.ensure(tiles * RT_QUEUE_LISTS))) return rc;
-    if (s->count_work && (rc = s->unit_cost.ensure(tiles * 112))) return rc;
-    if (rebuild && (rc = scene_ensure_refs(s))) return rc;
+    if ((rc = w->tile_list.ensure(tiles)) || (rc = w->tile_cost.ensure(tiles)) || (rc = w->queue_lists.ensure(tiles * RT_QUEUE_LISTS))) return rc;
+    if (s->count_work && (rc = w->unit_cost.ensure(tiles * 112))) return rc;
+    if (rebuild && (rc = scene_ensure_refs(s, *w))) return rc;
     const int slot = (int)(s->frames % RT_STATS_RING);
     s->built[slot] = rebuild;
     int build = 0;
-    if (rebuild) { build = s->build_clean ? 1 : 2; s->build_clean = false; }
-    if ((rc = render_frame(s, p, scene_mem(s), build, true, d_rgb_f32, d_rgb_u8, d_hit_id, st, s->stamps.p + 4 * slot, &s->start_is_trace[slot]))) return rc;
-    if (rebuild) { s->grid_valid = true; s->build_clean = true; s->grid_sorted = s->want_sorted(); }
+    if (rebuild) { build = w->build_clean ? 1 : 2; w->build_clean = false; }
+    if ((rc = render_frame(s, p, scene_mem(s, *w), build, w, d_rgb_f32, d_rgb_u8, d_hit_id, st, s->stamps.p + 4 * slot, &s->start_is_trace[slot]))) return rc;
+    if (rebuild) { w->grid_valid = true; w->build_clean = true; w->grid_sorted = s->want_sorted(); }
     s->frames++;
     s->last_params = *p;
-    return scene_leave_stream(s, st);
+    return scene_leave_stream(s, w, st);
 }
 
 // Variant of rt_render_device() that allocates nothing: the working memory of the frame (grid, voxel tables, reference
@@ -889,7 +958,76 @@ extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d
     m.tile_cap = RT_NOALLOC_MAX_TILES;
     m.unit_cost = nullptr;
     // one stream, no events, no side stream: kernels and memsets only
-    return render_frame(s, p, m, 2, false, d_rgb_f32, d_rgb_u8, d_hit_id, (hipStream_t)stream, nullptr, nullptr);
+    return render_frame(s, p, m, 2, nullptr, d_rgb_f32, d_rgb_u8, d_hit_id, (hipStream_t)stream, nullptr, nullptr);
+}
+
+// ---- several frames in flight ------------------------------------------------------------------
+extern "C" int rt_scene_set_frames_in_flight(rt_scene* s, int32_t n) {
+    if (!s || n < 1 || n > RT_MAX_IN_FLIGHT) return set_err(RT_ERR_INVALID, "rt_scene_set_frames_in_flight: 1..%d working sets", RT_MAX_IN_FLIGHT);
+    if (s->device >= 0) {
+        int dev = -1;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev != s->device) return set_err(RT_ERR_INVALID, "scene is bound to device %d, current device is %d", s->device, dev);
+        HIP_TRY(hipDeviceSynchronize());
+        for (int i = n; i < RT_MAX_IN_FLIGHT; ++i) s->sets[i].release();
+    }
+    // the streams seen so far are forgotten: the next frame on any stream takes the first set
+    for (WorkSet& w : s->sets) { w.stream_used = false; w.last_stream = nullptr; }
+    s->n_sets = n;
+    if (s->cur >= n) s->cur = 0;
+    return RT_OK;
+}
+
+extern "C" int32_t rt_scene_frames_in_flight(const rt_scene* s) { return s ? s->n_sets : 0; }
+
+// Streams that run side by side. The HIP runtime spreads the streams of a process over a few hardware queues (four by
+// default) and work of two streams on one queue runs in order, as if it were one stream; which queue a new stream lands
+// on depends on what the process created before. So candidates are created one at a time and each is kept only if a short
+// wait kernel on it overlaps in time with the same kernel on every stream kept so far.
+extern "C" int32_t rt_streams_create(int32_t n, void** streams) {
+    if (n < 1 || n > RT_MAX_IN_FLIGHT || !streams) return set_err(RT_ERR_INVALID, "rt_streams_create: 1..%d streams", RT_MAX_IN_FLIGHT);
+    {
+        int n_dev = 0;
+        hipError_t e0 = hipGetDeviceCount(&n_dev);
+        if (e0 != hipSuccess || n_dev <= 0) return set_err(RT_ERR_NO_DEVICE, "no HIP device: %s", e0 == hipSuccess ? "count is 0" : hipGetErrorString(e0));
+    }
+    const int max_candidates = 4 * RT_MAX_IN_FLIGHT;
+    const unsigned ticks = 20000;                 // 0.2 ms: long against the time between the two launches
+    hipStream_t kept[RT_MAX_IN_FLIGHT], rejected[4 * RT_MAX_IN_FLIGHT];
+    int n_kept = 0, n_rej = 0;
+    unsigned long long* d_stamps = nullptr;
+    hipError_t e = hipMalloc((void**)&d_stamps, 4 * sizeof(unsigned long long));
+    for (int c = 0; c < max_candidates && n_kept < n && e == hipSuccess; ++c) {
+        hipStream_t cand = nullptr;
+        if ((e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking)) != hipSuccess) break;
+        bool beside_all = true;
+        for (int k = 0; k < n_kept && beside_all && e == hipSuccess; ++k) {
+            unsigned long long t[4] = {0, 0, 0, 0};
+            e = rt_launch_probe_wait(d_stamps, ticks, kept[k]);
+            if (e == hipSuccess) e = rt_launch_probe_wait(d_stamps + 2, ticks, cand);
+            if (e == hipSuccess) e = hipStreamSynchronize(kept[k]);
+            if (e == hipSuccess) e = hipStreamSynchronize(cand);
+            if (e == hipSuccess) e = hipMemcpy(t, d_stamps, sizeof(t), hipMemcpyDeviceToHost);
+            beside_all = e == hipSuccess && t[2] < t[1] && t[0] < t[3];       // the two intervals intersect
+        }
+        if (beside_all && e == hipSuccess) kept[n_kept++] = cand;
+        else rejected[n_rej++] = cand;           // destroyed at the end: freeing a queue slot now would send the next candidate to it
+    }
+    for (int k = 0; k < n_rej; ++k) (void)hipStreamDestroy(rejected[k]);
+    if (d_stamps) (void)hipFree(d_stamps);
+    if (e != hipSuccess) {
+        for (int k = 0; k < n_kept; ++k) (void)hipStreamDestroy(kept[k]);
+        return set_err(RT_ERR_HIP, "rt_streams_create: %s", hipGetErrorString(e));
+    }
+    for (int k = 0; k < n_kept; ++k) streams[k] = (void*)kept[k];
+    return n_kept;
+}
+
+extern "C" int rt_streams_destroy(int32_t n, void* const* streams) {
+    if (n < 0 || (n > 0 && !streams)) return set_err(RT_ERR_INVALID, "rt_streams_destroy: bad argument");
+    for (int k = 0; k < n; ++k)
+        if (streams[k]) HIP_TRY(hipStreamDestroy((hipStream_t)streams[k]));
+    return RT_OK;
 }
 
 extern "C" int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_t* rgb_u8, int32_t* hit_id) {
@@ -908,7 +1046,7 @@ extern "C" int rt_render(rt_scene* s, const rt_params* p, float* rgb_f32, uint8_
     if (hit_id) HIP_TRY(hipMemcpy(hit_id, s->o_id.p, px * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipDeviceSynchronize());
     RtGrid g;
-    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&g, s->sets[s->cur].d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
     if (g.overflow) return set_err(RT_ERR_HIP, "grid reference capacity exceeded");
     return RT_OK;
 }
@@ -947,10 +1085,11 @@ extern "C" int rt_scene_last_stats(rt_scene* s, rt_frame_stats* out) { return rt
 
 extern "C" int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n) {
     if (!s || !out || n < 0) return set_err(RT_ERR_INVALID, "rt_scene_unit_costs: bad argument");
-    if (!s->unit_cost.p) return set_err(RT_ERR_INVALID, "no counting frame rendered yet");
+    const WorkSet& w = s->sets[s->cur];
+    if (!w.unit_cost.p) return set_err(RT_ERR_INVALID, "no counting frame rendered yet");
     HIP_TRY(hipDeviceSynchronize());
-    const size_t k = (size_t)n < s->unit_cost.cap ? (size_t)n : s->unit_cost.cap;
-    HIP_TRY(hipMemcpy(out, s->unit_cost.p, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const size_t k = (size_t)n < w.unit_cost.cap ? (size_t)n : w.unit_cost.cap;
+    HIP_TRY(hipMemcpy(out, w.unit_cost.p, k * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return (int)k;
 }
 
@@ -960,7 +1099,10 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     if (frames_back < 0 || frames_back >= RT_STATS_RING || (uint64_t)frames_back >= s->frames) return set_err(RT_ERR_INVALID, "frame %d is not in the stats ring", frames_back);
     const int slot = (int)((s->frames - 1 - (uint64_t)frames_back) % RT_STATS_RING);
     memset(out, 0, sizeof(*out));
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    {
+        int rc = scene_sync_streams(s);
+        if (rc) return rc;
+    }
     {
         // ticks of the 100 MHz real-time clock, written by the frame's kernels
         unsigned long long t[4];
@@ -974,8 +1116,8 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     if (!s->built[slot]) out->ms_build = 0.f;
     RtGrid g;
     unsigned long long c[24];
-    HIP_TRY(hipMemcpy(&g, s->d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&g, s->sets[s->cur].d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c, s->sets[s->cur].counters.p, sizeof(c), hipMemcpyDeviceToHost));
     for (int a = 0; a < 3; ++a) out->grid_n[a] = g.n[a];
     out->n_cells = (uint32_t)g.n_cells;
     out->n_refs = g.n_refs;
@@ -1006,9 +1148,12 @@ extern "C" int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out) {
     if (!s || !out) return set_err(RT_ERR_INVALID, "rt_scene_last_counts: bad argument");
     if (s->frames == 0) return set_err(RT_ERR_INVALID, "no frame rendered yet");
     memset(out, 0, sizeof(*out));
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    {
+        int rc = scene_sync_streams(s);
+        if (rc) return rc;
+    }
     unsigned long long c[24];
-    HIP_TRY(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c, s->sets[s->cur].counters.p, sizeof(c), hipMemcpyDeviceToHost));
     out->primary_entering = c[2]; out->steps_primary = c[3]; out->tests_primary = c[4];
     out->shadow_entering = c[5]; out->steps_shadow = c[6]; out->tests_shadow = c[7];
     out->sched_rounds = c[8]; out->sched_streams = c[9]; out->sched_lanes = c[10];

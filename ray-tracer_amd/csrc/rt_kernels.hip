@@ -2232,6 +2232,29 @@ hipError_t rt_noalloc_scratch(void** ptr) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// probe for rt_streams_create(): do two streams run side by side?
+// ------------------------------------------------------------------------------------------------
+// One wavefront that notes the 100 MHz clock, waits `ticks` of it (bounded by an iteration count as well, so that it ends
+// whatever the clock does) and notes it again. Two of these on two streams overlap in time exactly when the runtime has
+// put the streams on different hardware queues.
+__global__ void k_probe_wait(unsigned long long* stamps, unsigned int ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t = t0;
+    for (unsigned int it = 0; it < (1u << 22) && t - t0 < ticks; ++it) {
+        __builtin_amdgcn_s_sleep(32);
+        t = __builtin_amdgcn_s_memrealtime();
+    }
+    stamps[0] = t0;
+    stamps[1] = t;
+}
+
+hipError_t rt_launch_probe_wait(unsigned long long* stamps, unsigned int ticks, hipStream_t st) {
+    k_probe_wait<<<1, 64, 0, st>>>(stamps, ticks);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // band de-interleave after a gather to rank 0
 // ------------------------------------------------------------------------------------------------
 __global__ void k_deinterleave(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int width, int height, int part_count,
