@@ -1213,7 +1213,9 @@ __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* 
     if (blockIdx.x == 0 && threadIdx.x < RT_QUEUE_LISTS) {
         uint32_t sh = (uint32_t)((unit_shifts >> (4 * threadIdx.x)) & 15ull);
         if (adapt) {
-            uint32_t up = (2u * n >= 5u * (uint32_t)n_waves ? 1u : 0u) + (n >= 10u * (uint32_t)n_waves ? 1u : 0u);
+            // adapt == 2: other frames are in flight beside this one and fill the GPU while its last units run, so the
+            // largest units pay from fewer tiles per wavefront on
+            uint32_t up = (2u * n >= 5u * (uint32_t)n_waves ? 1u : 0u) + (n >= (adapt == 2 ? 8u : 10u) * (uint32_t)n_waves ? 1u : 0u);
             if (threadIdx.x < 8 && !(grid->n_refs < 2u * grid->n_cells)) up = up > 0u ? up - 1u : 0u;
             sh = sh > up ? sh - up : 0u;
         }
