@@ -254,6 +254,25 @@ def main():
         st_a = [scene.stats_at(i) for i in range(n_alone - 1)]
         ms_render_alone = float(np.mean([x["ms_render"] for x in st_a]))
         ms_build_alone = float(np.mean([x["ms_build"] for x in st_a]))
+    # Frame time when latency is what counts: the scene set up for one frame at a time (one working set; the trace kernel
+    # then takes the whole GPU and large meshes prepare their work list beside the grid build), frames issued back to back
+    # on one stream. Untimed by the driver.
+    one_at_a_time = None
+    if world == 1:
+        scene.set_frames_in_flight(1)
+        n_one = max(4, min(args.steps, 20))
+        for _ in range(2):
+            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_one):
+            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
+        torch.cuda.synchronize()
+        dt_one = (time.perf_counter() - t1) / n_one
+        st_o = [scene.stats_at(i) for i in range(n_one)]
+        one_at_a_time = {"ms_per_frame": round(dt_one * 1e3, 4), "mrays": round(rays_local / dt_one / 1e6, 2), "frames": n_one,
+                         "build": round(float(np.mean([x["ms_build"] for x in st_o])), 4), "render": round(float(np.mean([x["ms_render"] for x in st_o])), 4)}
+        scene.set_frames_in_flight(depth)
 
     # N > 1: the gathered, de-interleaved frame must be the frame one GPU renders alone (untimed check on rank 0)
     frame_check = None
@@ -402,6 +421,7 @@ def main():
                                  "as the frames of the timed region saw them, i.e. sharing the GPU with %d other frames" % (n_lanes - 1) if n_lanes > 1 else
                                  "first build kernel to the start of the trace kernel, trace kernel, their sum",
                          "alone": {"build": round(ms_build_alone, 4), "render": round(ms_render_alone, 4), "device_total": round(ms_build_alone + ms_render_alone, 4)},
+                         "one_at_a_time": one_at_a_time,
                          "with_host_writeback": wb["ms"] if wb else None},
             "host_writeback": wb,
             "stress": stress,
