@@ -3,10 +3,12 @@
 // (1.5,0,0), both coloured (255,0,0), render 512x512 and write ./test.ppm.
 #include "../../include/rt_amd.h"
 
+#include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -16,6 +18,7 @@ static void usage() {
     fprintf(stderr,
             "usage: rt [--obj PATH [--no-vt] [--color R G B] [--offset X Y Z]]... [--size W H] [--out FILE]\n"
             "          [--cam X Y Z] [--target X Y Z] [--up X Y Z] [--fov DEG] [--full-walk] [--stats]\n"
+            "          [--frames N [--in-flight D]]   (render the frame N times, D frames in flight, and print the frame rate)\n"
             "          [--parallel-shading [--light X Y Z] [--eps E] [--shadow-scale S] [--reflect-depth D]]\n"
             "          per mesh: [--scale N] [--material KD KS ALPHA KA KM REFLECTIVE]   (fast_trace of the Parallel tree)\n"
             "       with no --obj: spot_triangulated.obj and blub_triangulated.obj (+1.5 in x) from the working directory\n");
@@ -27,6 +30,7 @@ int main(int argc, char** argv) {
     std::vector<MeshArg> meshes;
     std::string out = "./test.ppm";
     bool stats = false;
+    int frames = 0, in_flight = 4;
     auto need = [&](int i, int n) { if (i + n >= argc) { usage(); exit(2); } };
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -55,6 +59,8 @@ int main(int argc, char** argv) {
         else if (a == "--fov") { need(i, 1); p.fov = (float)atof(argv[++i]); }
         else if (a == "--full-walk") p.walk_mode = RT_WALK_FULL;
         else if (a == "--stats") stats = true;
+        else if (a == "--frames") { need(i, 1); frames = atoi(argv[++i]); }
+        else if (a == "--in-flight") { need(i, 1); in_flight = atoi(argv[++i]); }
         else { usage(); return 2; }
     }
     if (meshes.empty()) {
@@ -73,8 +79,36 @@ int main(int argc, char** argv) {
         }
         if (n < 0) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
     }
-    int rc = rt_render_ppm(s, &p, out.c_str());
-    if (rc) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
+    if (frames > 0) {
+        // a stream of frames: frame k on lane k % D, each with its own grid build and its own RGB8 buffer on the device
+        void* lane[8] = {};
+        void* d_u8[8] = {};
+        if (rt_scene_upload(s) || rt_scene_set_frames_in_flight(s, in_flight)) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
+        const int n = rt_streams_create(in_flight, lane);
+        if (n < 1) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
+        const size_t bytes = (size_t)p.width * p.height * 3;
+        for (int k = 0; k < n; ++k)
+            if (hipMalloc(&d_u8[k], bytes) != hipSuccess) { fprintf(stderr, "rt: out of device memory\n"); return 1; }
+        double ms = 0;
+        for (int pass = 0; pass < 2; ++pass) {           // the first pass warms up
+            const int count = pass ? frames : 2 * n;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < count; ++k)
+                if (rt_render_device(s, &p, 1, nullptr, d_u8[k % n], nullptr, lane[k % n])) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
+            if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "rt: device error\n"); return 1; }
+            ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / count;
+        }
+        fprintf(stderr, "%d frames of %dx%d, %d in flight: %.4f ms per frame\n", frames, p.width, p.height, n, ms);
+        std::vector<unsigned char> img(bytes);
+        if (hipMemcpy(img.data(), d_u8[(frames - 1) % n], bytes, hipMemcpyDeviceToHost) != hipSuccess || rt_write_ppm_u8(out.c_str(), img.data(), p.width, p.height)) {
+            fprintf(stderr, "rt: cannot write %s\n", out.c_str()); return 1;
+        }
+        for (int k = 0; k < n; ++k) (void)hipFree(d_u8[k]);
+        (void)rt_streams_destroy(n, lane);
+    } else {
+        int rc = rt_render_ppm(s, &p, out.c_str());
+        if (rc) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
+    }
     if (stats) {
         rt_frame_stats st;
         if (rt_scene_last_stats(s, &st) == RT_OK)

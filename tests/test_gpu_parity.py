@@ -430,6 +430,18 @@ def test_command_line_program_is_a_drop_in_for_main(tmp_path):
     assert hashlib.md5((tmp_path / "test.ppm").read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
 
 
+def test_command_line_program_renders_a_stream_of_frames(tmp_path):
+    """--frames N --in-flight D: the same frame N times on D lanes; the image it leaves is the reference's."""
+    import hashlib, shutil, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "ray-tracer_amd", "rt")
+    shutil.copy(SPOT, tmp_path / "spot_triangulated.obj")
+    shutil.copy(BLUB, tmp_path / "blub_triangulated.obj")
+    r = subprocess.run([exe, "--frames", "11", "--in-flight", "3"], cwd=tmp_path, check=True, timeout=100, capture_output=True, text=True)
+    assert "3 in flight" in r.stderr and "ms per frame" in r.stderr
+    assert hashlib.md5((tmp_path / "test.ppm").read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
+
+
 def test_unit_diagnostics_are_consistent(rt):
     """rt_scene_unit_costs after a counting frame: one record per work unit, and the per-unit numbers add up to the
     per-tile and per-frame ones (layout in include/rt_amd.h)."""
