@@ -79,3 +79,38 @@ def test_frames_in_flight_equal_frames_one_at_a_time(rt, depth, rebuild):
         rt.destroy_streams(hs)
     with pytest.raises(rt.RtError):
         s.set_frames_in_flight(0)
+
+
+def test_crowded_grid_in_flight(rt):
+    """A mesh of 909,312 triangles (crowded voxels: run culling, the kernel variant without the small-voxel path, the unit
+    sizes and the wavefront share chosen for frames in flight) from two cameras, four frames in flight against one at a time."""
+    import torch
+    tmp = rt.Scene(); tmp.load_mesh(BLUB); v9 = rt.subdivide(tmp.triangles(), 3); tmp.close()
+    s = rt.Scene(); s.add_triangles(v9); s.upload()
+    views = [rt.default_params(1920, 1080), rt.default_params(1280, 720, cam_pos=(1.0, 1.6, 1.0), cam_target=(0.0, 0.2, -0.45)),
+             rt.default_params(1920, 1080, walk_mode=rt.RT_WALK_FULL), rt.default_params(800, 600, cam_pos=(-2.0, 3.0, 2.0))]
+    want = []
+    for p in views:
+        b = _buffers(rt, torch, p)
+        s.render_device(p, rebuild_grid=True, d_rgb=b[0].data_ptr(), d_u8=b[1].data_ptr(), d_ids=b[2].data_ptr())
+        torch.cuda.synchronize()
+        want.append([t.cpu().numpy() for t in b])
+    s.set_frames_in_flight(4)
+    hs = rt.create_streams(4)
+    try:
+        order = [0, 1, 2, 3, 1, 0, 3, 2, 2, 1]
+        bufs = [_buffers(rt, torch, views[v]) for v in order]
+        torch.cuda.synchronize()
+        for k, v in enumerate(order):
+            b = bufs[k]
+            s.render_device(views[v], rebuild_grid=True, d_rgb=b[0].data_ptr(), d_u8=b[1].data_ptr(), d_ids=b[2].data_ptr(), stream=hs[k % len(hs)])
+        torch.cuda.synchronize()
+        for k, v in enumerate(order):
+            rgb, u8, ids = [t.cpu().numpy() for t in bufs[k]]
+            assert (ids >= 0).sum() > 5000
+            assert np.array_equal(ids, want[v][2]), k
+            assert np.array_equal(rgb.view(np.uint32), want[v][0].view(np.uint32)), k
+            assert np.array_equal(u8, want[v][1]), k
+    finally:
+        torch.cuda.synchronize()
+        rt.destroy_streams(hs)

@@ -16,9 +16,10 @@ for depth in [int(x) for x in sys.argv[3:]]:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(m):
             scene.render_device(p, rebuild_grid=True, d_u8=outs[i % len(hs)].data_ptr(), stream=hs[i % len(hs)])
-        torch.cuda.synchronize(); return (time.perf_counter() - t0) / m * 1e3
+        t_host = (time.perf_counter() - t0) / m * 1e3
+        torch.cuda.synchronize(); run.host = t_host; return (time.perf_counter() - t0) / m * 1e3
     run(3 * depth)
     t = run(96)
     lat = [scene.stats_at(k)["ms_total"] for k in range(32)]
-    print(w, "parts", parts, "depth", depth, "streams", len(hs), "%.4f ms/frame, frame latency %.3f ms" % (t, sum(lat) / len(lat)), flush=True)
+    print(w, "parts", parts, "depth", depth, "streams", len(hs), "%.4f ms/frame, frame latency %.3f ms, host enqueue %.4f ms/frame" % (t, sum(lat) / len(lat), run.host), flush=True)
     rt.destroy_streams(hs)
