@@ -66,7 +66,9 @@ struct RtSceneDev {
     const RtGrid* grid;
     const uint32_t* cell_start;   // n_cells + 1
     const uint32_t* occupancy;    // 1 bit per cell
-    const float4* recs;           // 3 float4 per reference, cell-major, ascending triangle index in a cell
+    const float4* tri_rec;        // 3 float4 per triangle, triangle order
+    const float4* recs;           // cell-major voxel lists: 3 float4 per reference, or (indexed) one uint32 triangle index per reference
+    uint32_t indexed;
     const float4* blk_bounds;     // 3 float4 per aligned run of 64 references: {lo.xyz, max |coord|}, {hi.xyz, slab min}, {slab normal, slab max}
 };
 
@@ -120,6 +122,7 @@ struct RtBuildDev {
     uint32_t ref_cap;
     unsigned long long* counters;
     unsigned long long* stamp;    // when not NULL, the first kernel of the build writes the 100 MHz real-time clock here (frame start)
+    int32_t indexed;              // 1: recs holds one uint32 triangle index per reference instead of the 48-byte record
     int32_t sorted;               // 1: voxel lists in ascending triangle index (scatter, row sort, ranking; needs ref_tri, ref_cell,
                                   // row_minmax); 0: records scattered straight into their voxels, in no particular order
 };
@@ -164,7 +167,7 @@ hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st);   // scatter, p
 hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtRenderWork wk, hipStream_t st);   // classify, estimate, cost classes
 hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtOutputs o, RtRenderWork wk, hipStream_t st);
 size_t rt_trace_lds_bytes(int bitmap_words);
-hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32_t n_refs, hipStream_t st);
+hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32_t n_refs, int indexed, hipStream_t st);
 hipError_t rt_launch_probe_wait(unsigned long long* stamps, unsigned int ticks, hipStream_t st);   // stamps[0..1]: start and end on the 100 MHz clock
 hipError_t rt_launch_selftest_div(const double* num, const double* den, uint32_t n, uint32_t* mismatches, hipStream_t st);
 hipError_t rt_launch_deinterleave(const void* src, void* dst, int32_t width, int32_t height, int32_t part_count,

@@ -86,6 +86,7 @@ struct WorkSet {
     bool grid_valid = false;
     bool build_clean = false;          // the last grid build ran to its end and left its counters reset for the next one
     bool grid_sorted = false;          // how the current grid was built
+    bool grid_indexed = false;         // and what its voxel lists hold: triangle indices, or the test records themselves
     hipStream_t last_stream = nullptr; // stream of the last frame or grid build on this set
     bool stream_used = false;
     uint64_t last_ticket = 0;          // when it was last used, to find the set that has been idle longest
@@ -99,7 +100,7 @@ struct WorkSet {
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side_stream) (void)hipStreamDestroy(side_stream);
         ev_fork = ev_join = nullptr; side_stream = nullptr;
-        zeroed = grid_valid = build_clean = grid_sorted = stream_used = false;
+        zeroed = grid_valid = build_clean = grid_sorted = grid_indexed = stream_used = false;
         last_stream = nullptr;
     }
 };
@@ -143,6 +144,7 @@ struct rt_scene {
     bool sched_adapt = true;               // off when RT_SHIFTS gives the unit sizes explicitly
     float est_w[4] = {1.f, 500.f, 0.f, 700.f};    // cost estimate weights: primary triangles, primary voxels, shadow triangles, shadow voxels
     int side_stream_override = -1;           // RT_SIDE_STREAM: 0 / 1, -1 = the library decides
+    int indexed_override = -1;               // RT_INDEXED_RECS: 0 / 1, -1 = the library decides
     rt_params last_params;
     // experiment overrides, read once when the scene is created: RT_OWN_PATH (-1 = the library decides), RT_CULL_MIN
     // (1..65535), RT_CULL_LANE_RUNS (0..64), RT_BLOCKS_PER_CU (0 = no cap)
@@ -188,6 +190,7 @@ extern "C" rt_scene* rt_scene_create(void) {
         s->blocks_per_cu_cap = env_int("RT_BLOCKS_PER_CU", 1, 64, 0);
         s->force_sorted = env_int("RT_SORTED_BUILD", 0, 1, -1);
         s->side_stream_override = env_int("RT_SIDE_STREAM", 0, 1, -1);
+        s->indexed_override = env_int("RT_INDEXED_RECS", 0, 1, -1);
     }
     return s;
 }
@@ -440,6 +443,7 @@ struct FrameMem {
     float4 *recs = nullptr, *blk_bounds = nullptr;
     size_t ref_cap = 0;                      // references recs and blk_bounds can hold
     bool sorted = false;                     // build the voxel lists in ascending triangle index (needs ref_tri, ref_cell, row_minmax)
+    bool indexed = false;                    // the voxel lists hold triangle indices instead of copies of the 48-byte test records
     unsigned long long* counters = nullptr;  // RT_COUNTER_WORDS
     uint32_t *tile_list = nullptr, *tile_cost = nullptr, *queue_lists = nullptr;
     size_t tile_cap = 0;                     // tiles the three lists above can hold (queue_lists: RT_QUEUE_LISTS times as many)
@@ -447,8 +451,9 @@ struct FrameMem {
 };
 #define RT_COUNTER_WORDS 88                  // 24 frame counters, 32 work-list words (64 x u32), 32 partial sums of the cost estimate
 
-static FrameMem scene_mem(const rt_scene* s, const WorkSet& w) {
+static FrameMem scene_mem(const rt_scene* s, const WorkSet& w, bool indexed = false) {
     FrameMem m;
+    m.indexed = indexed;
     m.grid = w.d_grid.p; m.bounds_enc = w.bounds_enc.p; m.cell_count = w.cell_count.p; m.cell_start = w.cell_start.p;
     m.block_sums = w.block_sums.p; m.occupancy = w.occupancy.p;
     m.ref_tri = w.ref_tri.p; m.ref_cell = w.ref_cell.p; m.row_minmax = w.row_minmax.p; m.recs = w.recs.p; m.blk_bounds = w.blk_bounds.p;
@@ -492,6 +497,7 @@ static RtBuildDev build_args(rt_scene* s, const FrameMem& m) {
     b.counters = m.counters;
     b.stamp = nullptr;
     b.sorted = m.sorted ? 1 : 0;
+    b.indexed = m.indexed ? 1 : 0;
     return b;
 }
 
@@ -657,6 +663,7 @@ static int scene_build_grid_async(rt_scene* s, WorkSet& w, hipStream_t st) {
     w.grid_valid = true;
     w.build_clean = true;
     w.grid_sorted = s->want_sorted();
+    w.grid_indexed = false;
     return RT_OK;
 }
 
@@ -708,7 +715,7 @@ extern "C" int rt_scene_get_csr(rt_scene* s, uint32_t* cell_start, uint32_t* cel
         DevBuf<uint32_t> tmp;
         int rc = tmp.ensure(g.n_refs);
         if (rc) return rc;
-        hipError_t e = rt_launch_extract_cell_tris(w.recs.p, tmp.p, g.n_refs, nullptr);
+        hipError_t e = rt_launch_extract_cell_tris(w.recs.p, tmp.p, g.n_refs, w.grid_indexed ? 1 : 0, nullptr);
         if (e == hipSuccess) e = hipMemcpy(cell_tris, tmp.p, (size_t)g.n_refs * sizeof(uint32_t), hipMemcpyDeviceToHost);
         tmp.release();
         if (e != hipSuccess) return set_err(RT_ERR_HIP, "csr read-back: %s", hipGetErrorString(e));
@@ -814,10 +821,12 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
 
     RtSceneDev sd;
     sd.v0 = s->v0.p; sd.v1 = s->v1.p; sd.v2 = s->v2.p;
+    sd.tri_rec = s->tri_rec.p;
     sd.mesh_color = s->d_mesh_color.p;
     sd.mesh_mat = s->d_mesh_mat.p;
     sd.n_tris = (uint32_t)s->n_tris();
     sd.grid = m.grid; sd.cell_start = m.cell_start; sd.occupancy = m.occupancy; sd.recs = m.recs; sd.blk_bounds = m.blk_bounds;
+    sd.indexed = m.indexed ? 1u : 0u;
     RtShade sh;
     for (int a = 0; a < 3; ++a) sh.light[a] = p->light_pos[a];
     sh.kd = p->kd; sh.ks = p->ks; sh.ka = p->ka; sh.spec_alpha = p->spec_alpha;
@@ -913,7 +922,11 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     hipStream_t st = (hipStream_t)stream;
     WorkSet* w = nullptr;
     if ((rc = scene_enter_stream(s, st, &w))) return rc;
-    const bool rebuild = rebuild_grid || !w->grid_valid || w->grid_sorted != s->want_sorted();
+    // A rank's share of a frame on several GPUs: the grid build is the same for every share while the trace shrinks with it,
+    // so there the voxel lists hold triangle indices (build 0.23 -> 0.18 ms on the 3.6 M-triangle stand-in, trace 2...5 %
+    // slower: a gain from two GPUs on, a loss for whole frames).
+    const bool indexed = s->indexed_override >= 0 ? s->indexed_override != 0 : p->part_count > 1;
+    const bool rebuild = rebuild_grid || !w->grid_valid || w->grid_sorted != s->want_sorted() || w->grid_indexed != indexed;
     // working memory of the frame, grown when the triangle list or the frame size has grown
     const size_t tiles = frame_tiles(p);
     if ((rc = w->tile_list.ensure(tiles)) || (rc = w->tile_cost.ensure(tiles)) || (rc = w->queue_lists.ensure(tiles * RT_QUEUE_LISTS))) return rc;
@@ -923,8 +936,8 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     s->built[slot] = rebuild;
     int build = 0;
     if (rebuild) { build = w->build_clean ? 1 : 2; w->build_clean = false; }
-    if ((rc = render_frame(s, p, scene_mem(s, *w), build, w, d_rgb_f32, d_rgb_u8, d_hit_id, st, s->stamps.p + 4 * slot, &s->start_is_trace[slot]))) return rc;
-    if (rebuild) { w->grid_valid = true; w->build_clean = true; w->grid_sorted = s->want_sorted(); }
+    if ((rc = render_frame(s, p, scene_mem(s, *w, indexed), build, w, d_rgb_f32, d_rgb_u8, d_hit_id, st, s->stamps.p + 4 * slot, &s->start_is_trace[slot]))) return rc;
+    if (rebuild) { w->grid_valid = true; w->build_clean = true; w->grid_sorted = s->want_sorted(); w->grid_indexed = indexed; }
     s->frames++;
     s->last_params = *p;
     return scene_leave_stream(s, w, st);

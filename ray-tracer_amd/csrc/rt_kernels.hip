@@ -84,6 +84,15 @@ hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh,
     return hipGetLastError();
 }
 
+// Where the record of reference p lives. Copied records: the voxel lists hold the 48-byte test records themselves, a run
+// of 64 is one contiguous 3 KB read. Indexed records: the lists hold triangle indices (4 bytes per reference) and the
+// records stay in triangle order; the build writes and reads a twelfth of the bytes, the render kernel pays a dependent
+// load and a gather per run. The host picks per frame (RtBuildDev::indexed, RtSceneDev::indexed).
+__device__ __forceinline__ const float4* rec_ptr(const RtSceneDev& s, uint32_t p) {
+    return s.indexed ? s.tri_rec + 3ull * reinterpret_cast<const uint32_t*>(s.recs)[p] : s.recs + 3ull * p;
+}
+#define RT_REC_PTR(s, p) rec_ptr((s), (p))
+
 // ------------------------------------------------------------------------------------------------
 // grid build, Serial/grid.h:79-153, as count / prefix-scan / scatter
 // ------------------------------------------------------------------------------------------------
@@ -403,8 +412,10 @@ __global__ void __launch_bounds__(256) k_scatter_emit(RtBuildDev b) {
     float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
     if (valid) {
         tri_voxel_range(b, g, i, vmin, vmax);
-        const float4* r = b.tri_rec + 3ull * i;
-        rec0 = r[0]; rec1 = r[1]; rec2 = r[2];
+        if (!b.indexed) {
+            const float4* r = b.tri_rec + 3ull * i;
+            rec0 = r[0]; rec1 = r[1]; rec2 = r[2];
+        }
     }
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
@@ -423,8 +434,12 @@ __global__ void __launch_bounds__(256) k_scatter_emit(RtBuildDev b) {
         if (act && lane == leader) old = atomicSub(&b.cell_count[c], group);
         old = (uint32_t)__shfl((int)old, leader);
         if (act) {
-            float4* o = b.recs + 3ull * (start + old - 1u - rank);
-            o[0] = rec0; o[1] = rec1; o[2] = rec2;
+            if (b.indexed) {
+                reinterpret_cast<uint32_t*>(b.recs)[start + old - 1u - rank] = i;
+            } else {
+                float4* o = b.recs + 3ull * (start + old - 1u - rank);
+                o[0] = rec0; o[1] = rec1; o[2] = rec2;
+            }
         }
     }
 }
@@ -443,15 +458,21 @@ __global__ void __launch_bounds__(256) k_scatter_emit_wide(RtBuildDev b) {
     int vmin[3], vmax[3];
     tri_voxel_range(b, g, i, vmin, vmax);
     const float4* rr = b.tri_rec + 3ull * i;
-    const float4 rec0 = rr[0], rec1 = rr[1], rec2 = rr[2];
+    float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
+    if (!b.indexed) { rec0 = rr[0]; rec1 = rr[1]; rec2 = rr[2]; }
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1, exy = ex * ey;
     const int n = exy * (vmax[2] - vmin[2] + 1);
     for (int r = lane; r < n; r += 64) {
         const int z = r / exy, q = r - z * exy, y = q / ex, x = q - y * ex;
         const int c = (vmin[2] + z) * nxy + (vmin[1] + y) * nx + (vmin[0] + x);
-        float4* o = b.recs + 3ull * (b.cell_start[c] + atomicSub(&b.cell_count[c], 1u) - 1u);
-        o[0] = rec0; o[1] = rec1; o[2] = rec2;
+        const uint32_t pos = b.cell_start[c] + atomicSub(&b.cell_count[c], 1u) - 1u;
+        if (b.indexed) {
+            reinterpret_cast<uint32_t*>(b.recs)[pos] = i;
+        } else {
+            float4* o = b.recs + 3ull * pos;
+            o[0] = rec0; o[1] = rec1; o[2] = rec2;
+        }
     }
 }
 
@@ -575,7 +596,7 @@ __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
         const uint32_t c = cur.c, me = cur.me, beg = cur.beg, end = cur.end;
         // the triangle's record is requested now and written once the rank is known
         float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
-        if (valid) { const float4* r = b.tri_rec + 3ull * me; rec0 = r[0]; rec1 = r[1]; rec2 = r[2]; }
+        if (valid && !b.indexed) { const float4* r = b.tri_rec + 3ull * me; rec0 = r[0]; rec1 = r[1]; rec2 = r[2]; }
         uint32_t rank = 0;
         unsigned long long rem = __ballot(valid);
         while (rem) {
@@ -635,7 +656,10 @@ __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
                 }
             }
         }
-        if (valid) { float4* o = b.recs + 3ull * (beg + rank); o[0] = rec0; o[1] = rec1; o[2] = rec2; }
+        if (valid) {
+            if (b.indexed) reinterpret_cast<uint32_t*>(b.recs)[beg + rank] = me;
+            else { float4* o = b.recs + 3ull * (beg + rank); o[0] = rec0; o[1] = rec1; o[2] = rec2; }
+        }
     }
 }
 
@@ -679,7 +703,8 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
             // the vertices as the record gives them: v0, v0 - e1, v0 - e2. Rebuilding v1 and v2 from the rounded edge
             // vectors is off by at most one unit in the last place of the larger operand, two orders of magnitude below
             // the margin the box and slab tests add.
-            const float4 r0 = b.recs[3ull * p], r1 = b.recs[3ull * p + 1], r2 = b.recs[3ull * p + 2];
+            const float4* rp = b.indexed ? b.tri_rec + 3ull * reinterpret_cast<const uint32_t*>(b.recs)[p] : b.recs + 3ull * p;
+            const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
             vx[0] = r0.x; vy[0] = r0.y; vz[0] = r0.z;
             vx[1] = r0.x - r1.x; vy[1] = r0.y - r1.y; vz[1] = r0.z - r1.z;
             vx[2] = r0.x - r2.x; vy[2] = r0.y - r2.y; vz[2] = r0.z - r2.z;
@@ -788,14 +813,14 @@ hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st) {
     return hipGetLastError();
 }
 
-__global__ void k_extract_cell_tris(const float4* __restrict__ recs, uint32_t* out, uint32_t n) {
+__global__ void k_extract_cell_tris(const float4* __restrict__ recs, uint32_t* out, uint32_t n, int indexed) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = __float_as_uint(recs[3ull * i].w);
+    if (i < n) out[i] = indexed ? reinterpret_cast<const uint32_t*>(recs)[i] : __float_as_uint(recs[3ull * i].w);
 }
 
-hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32_t n_refs, hipStream_t st) {
+hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32_t n_refs, int indexed, hipStream_t st) {
     if (n_refs == 0) return hipSuccess;
-    k_extract_cell_tris<<<(n_refs + 255) / 256, 256, 0, st>>>(recs, out, n_refs);
+    k_extract_cell_tris<<<(n_refs + 255) / 256, 256, 0, st>>>(recs, out, n_refs, indexed);
     return hipGetLastError();
 }
 
@@ -1576,7 +1601,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                         int pass_id = -1;                       // record index of a passing triangle
                         double t_p = 0.0;
                         if (own_r && p < ce) {
-                            const float4* rr = s.recs + 3ull * p;
+                            const float4* rr = RT_REC_PTR(s, p);
                             const TriRec t = unpack_rec(rr[0], rr[1], rr[2]);
                             if (COUNT) ++own_tests;
                             const double sx = t.v0x - rox, sy = t.v0y - roy, sz = t.v0z - roz;       // float subtractions, then widened
@@ -1626,7 +1651,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     }
                 } else if (own) {
                     for (uint32_t p = cbeg; p < cend; ++p) {
-                        const float4* r = s.recs + 3ull * p;
+                        const float4* r = RT_REC_PTR(s, p);
                         const TriRec t = unpack_rec(r[0], r[1], r[2]);
                         if (COUNT) ++own_tests;
                         const double sx = t.v0x - ox, sy = t.v0y - oy, sz = t.v0z - oz;          // float subtractions, then widened
@@ -1704,7 +1729,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         };
         auto load_item = [&](const Item& it, float4& r0, float4& r1, float4& r2) {
             const uint32_t p = it.base + lane;
-            const float4* r = s.recs + 3ull * ((p >= it.b && p < it.e) ? p : it.b);
+            const float4* r = RT_REC_PTR(s, ((p >= it.b && p < it.e) ? p : it.b));
             r0 = r[0]; r1 = r[1]; r2 = r[2];
         };
         // Two runs are kept in flight: the records of item i+2 are requested before item i is tested, so a load has the

@@ -237,6 +237,43 @@ def test_record_order_inside_a_voxel_does_not_matter(rt, O, plane10, monkeypatch
         s.close()
 
 
+@pytest.mark.parametrize("sorted_build", ["0", "1"])
+def test_indexed_voxel_lists_give_the_same_frames(rt, O, plane10, monkeypatch, sorted_build):
+    """Voxel lists that hold triangle indices instead of copies of the test records (what a rank's share of a frame on
+    several GPUs uses; RT_INDEXED_RECS=1 forces it for whole frames): goldens of a sparse and a flat scene, a crowded mesh
+    with duplicated triangles against the oracle in both record orders, and the list read-back."""
+    import torch
+    monkeypatch.setenv("RT_INDEXED_RECS", "1")
+    monkeypatch.setenv("RT_SORTED_BUILD", sorted_build)
+    for name in ("main_512x512", "plane10_480x270"):
+        s, W, H, cam = _scene(rt, name, plane10)
+        rgb, u8, ids = s.render(rt.default_params(W, H, **cam_kwargs(cam)), want_u8=True)
+        g_ids, g_rgb = golden(name)
+        check_image(rgb, ids, g_rgb, g_ids)
+        start, tris = s.grid_csr()
+        monkeypatch.setenv("RT_INDEXED_RECS", "0")
+        s2, _, _, _ = _scene(rt, name, plane10)
+        s2.build_grid()
+        start2, tris2 = s2.grid_csr()
+        monkeypatch.setenv("RT_INDEXED_RECS", "1")
+        assert np.array_equal(start, start2) and np.array_equal(tris, tris2)
+        s.close(); s2.close()
+    tmp = rt.Scene(); tmp.load_mesh(BLUB); v9 = rt.subdivide(tmp.triangles(), 2).copy(); tmp.close()
+    v9[:, 0::3] += 1.5
+    v9 = np.concatenate([v9, v9[::7], v9[::5]])
+    o = O.OracleScene(); o.add_obj(SPOT); o.add_triangles(v9, (30, 200, 90))
+    W, H = 480, 300
+    o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0))
+    s = rt.Scene(); s.load_mesh(SPOT); s.add_triangles(v9, (30, 200, 90))
+    p = rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL)
+    rgb_d = torch.empty((H, W, 3), dtype=torch.float32, device="cuda"); ids_d = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        s.render_device(p, rebuild_grid=True, d_rgb=rgb_d.data_ptr(), d_ids=ids_d.data_ptr())
+        torch.cuda.synchronize()
+        check_image(rgb_d.cpu().numpy(), ids_d.cpu().numpy(), o_rgb, o_ids)
+    s.close()
+
+
 def test_scene_grows_between_frames(rt, plane10):
     """The build kernels leave their counters reset for the next build of the scene; a triangle list that grows after
     frames have been rendered starts from scratch and gives the frames of a scene that was loaded in one go."""
