@@ -169,8 +169,12 @@ def main():
     if rehearsal:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_EXCHANGE=1: run the exchange step (process group, gather, de-interleave, frame check) with one rank too,
+    # to exercise that code path on a box with a single GPU. Its numbers are those of a one-GPU frame plus a no-op gather.
+    multi = world > 1 or os.environ.get("RT_BENCH_FORCE_EXCHANGE", "") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -198,13 +202,13 @@ def main():
     part_bufs = [torch.empty((rows, W, 3), dtype=torch.uint8, device=dev) for _ in lanes]
     part_u8 = part_bufs[0]
     frame_bufs = [torch.empty((H, W, 3), dtype=torch.uint8, device=dev) for _ in lanes] if rank == 0 else None
-    gathered = [torch.empty((world, rows, W, 3), dtype=torch.uint8, device=dev) for _ in lanes] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty((world, rows, W, 3), dtype=torch.uint8, device=dev) for _ in lanes] if (multi and rank == 0) else None
     torch.cuda.synchronize()
 
     def step(k):
         b = k % n_lanes
         scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[b].data_ptr(), stream=lane_handles[b])
-        if world > 1:
+        if multi:
             with torch.cuda.stream(lanes[b]):
                 if rehearsal:
                     lanes[b].synchronize()
@@ -218,7 +222,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -230,7 +234,7 @@ def main():
         step(k)
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -276,7 +280,7 @@ def main():
 
     # N > 1: the gathered, de-interleaved frame must be the frame one GPU renders alone (untimed check on rank 0)
     frame_check = None
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         p1 = rt.default_params(W, H, walk_mode=walk, part_index=0, part_count=1, **pkw)
         single = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
         scene.render_device(p1, rebuild_grid=False, d_u8=single.data_ptr(), stream=stream)
@@ -364,7 +368,7 @@ def main():
                   "roofline_frac": round((f32s / PEAK_FP32 + f64s / PEAK_FP64) / (ms_r * 1e-3), 5)}
 
     tot = torch.tensor([rays_local, hits_local], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     rays_total, hits_total = float(tot[0].item()), float(tot[1].item())
 
@@ -410,7 +414,7 @@ def main():
             "dtype": "f32+f64",
             "data": "synthetic" if "STAND-IN" in label or "plane" in label else "reference meshes",
             "config": {"workload": label, "walk": args.walk, "rays_per_frame": int(rays_total), "hits": int(hits_total),
-                       "frame": "grid build + render + RGB8 framebuffer" + (" + RCCL gather + de-interleave" if world > 1 else ""),
+                       "frame": "grid build + render + RGB8 framebuffer" + (" + RCCL gather + de-interleave" if multi else ""),
                        "frames_in_flight": n_lanes,
                        "pipeline": ("frame k runs on stream k %% %d with its own working set and output buffers; every frame builds its own grid; "
                                     "value = frames completed / wall time" % n_lanes) if n_lanes > 1 else "one frame at a time on one stream",
@@ -452,7 +456,7 @@ def main():
         if not args.no_cpu:
             out["parity"], out["cpu_baseline"] = cpu_baseline(rt, scene, pkw, W, H, walk)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

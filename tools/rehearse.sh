@@ -7,3 +7,8 @@ for n in "$@"; do
 import json,sys
 d=json.loads([l for l in open('gpurun_out/rehearsal_$n.json') if l.startswith('{')][-1]); print('ranks', d['n_gpus'], 'frame_check', d['frame_check'], 'ms', d['ms_per_step'], d['frame_ms'])"
 done
+# the same path through RCCL itself, one rank (process group on the nccl backend, gather on the lanes' streams, frame check)
+RT_BENCH_FORCE_EXCHANGE=1 timeout -k 10 280 python bench.py --no-cpu --no-extras --steps 12 > gpurun_out/rehearsal_rccl1.json 2> gpurun_out/rehearsal_rccl1.err || { tail -20 gpurun_out/rehearsal_rccl1.err; exit 1; }
+python3 -c "
+import json
+d=json.loads([l for l in open('gpurun_out/rehearsal_rccl1.json') if l.startswith('{')][-1]); print('rccl, 1 rank: frame_check', d['frame_check'], 'ms', d['ms_per_step'])"
