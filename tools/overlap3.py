@@ -15,7 +15,7 @@ for depth in [int(x) for x in sys.argv[3:]]:
     def run(m):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(m):
-            scene.render_device(p, rebuild_grid=True, d_u8=outs[i % len(hs)].data_ptr(), stream=hs[i % len(hs)])
+            scene.render_device(p, rebuild_grid=os.environ.get("RT_NO_REBUILD", "") != "1", d_u8=outs[i % len(hs)].data_ptr(), stream=hs[i % len(hs)])
         t_host = (time.perf_counter() - t0) / m * 1e3
         torch.cuda.synchronize(); run.host = t_host; return (time.perf_counter() - t0) / m * 1e3
     run(3 * depth)
