@@ -809,7 +809,10 @@ hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st) {
         k_row_sort<<<1024, 256, 0, st>>>(b);
         k_order_emit<<<2048, 256, 0, st>>>(b);
     }
-    k_block_bounds<<<1024, 256, 0, st>>>(b);
+    // one wavefront per run where the capacity allows that many runs (a wavefront's runs are a chain of memory round trips:
+    // 16 runs per wavefront take 63 us on the 3.6 M-triangle stand-in, 4 runs 52 us)
+    const uint32_t bb_blocks = (b.ref_cap / 64u + 4u) / 4u;
+    k_block_bounds<<<bb_blocks < 1u ? 1u : (bb_blocks > 4096u ? 4096u : bb_blocks), 256, 0, st>>>(b);
     return hipGetLastError();
 }
 
