@@ -7,7 +7,7 @@ P[2]="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS
 P[3]="SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"
 P[4]="SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F32"
 for k in 1 2 3 4; do
-  timeout -s KILL 120 rocprofv3 --pmc ${P[$k]} --kernel-trace --output-format csv -d $O/pass$k -o pmc -- python3 bench.py --no-cpu --no-extras --steps 2 --warmup 1 --workload $W > $O/pass$k.json 2> $O/pass$k.err || { tail -3 $O/pass$k.err; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc ${P[$k]} --kernel-trace --output-format csv -d $O/pass$k -o pmc -- python3 bench.py --no-cpu --no-extras --in-flight 1 --steps 2 --warmup 1 --workload $W > $O/pass$k.json 2> $O/pass$k.err || { tail -3 $O/pass$k.err; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections

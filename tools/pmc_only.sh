@@ -1,11 +1,6 @@
 #!/bin/bash
-# Everything under profiles/ for one round, run on the GPU box from the repository root: ROUND=r02 tools/round_artefacts.sh
-# kernel stats + bench lines of the four workloads, the default bench line with the CPU leg, HBM traffic of k_trace
-# (FETCH_SIZE / WRITE_SIZE passes) and the SQ counter passes. Results land in gpurun_out/artefacts/ (copy them to profiles/).
+# the counter part of tools/round_artefacts.sh alone: HBM traffic and SQ counter passes of k_trace (one frame at a time)
 R=$PWD; export ROUND=${ROUND:-r02}; A=$R/gpurun_out/artefacts; mkdir -p $A
-./tools/final.sh nefertiti4k plane4k spot1080 main512 || exit 1
-cp gpurun_out/final/${ROUND}_final_* $A/
-timeout -k 10 300 python -u bench.py > $A/${ROUND}_final_default_bench_with_cpu.json 2> $A/default.err || { tail -5 $A/default.err; exit 1; }
 python3 - <<PY > $A/traffic.json
 import json, subprocess, sys
 out = {}
@@ -25,4 +20,3 @@ for w in nefertiti4k plane4k spot1080; do
   cp gpurun_out/pmc_${ROUND}_$w/summary.csv $A/${ROUND}_pmc_${w}_k_trace.csv
   for k in 1 2 3 4; do cp gpurun_out/pmc_${ROUND}_$w/pass$k/pmc_counter_collection.csv $A/${ROUND}_pmc_${w}_pass$k.csv; done
 done
-ls $A

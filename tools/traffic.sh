@@ -3,7 +3,7 @@
 #   tools/traffic.sh <workload>  ->  gpurun_out/traffic_<workload>.json
 export TMPDIR=/tmp; R=$PWD; W=$1; O=$R/gpurun_out/traffic_$W; mkdir -p $O
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 120 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$C -o pmc -- python3 bench.py --no-cpu --no-extras --steps 3 --warmup 1 --workload $W > $O/$C.json 2> $O/$C.err || { tail -3 $O/$C.err; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/$C -o pmc -- python3 bench.py --no-cpu --no-extras --in-flight 1 --steps 3 --warmup 1 --workload $W > $O/$C.json 2> $O/$C.err || { tail -3 $O/$C.err; exit 1; }
 done
 python3 - <<PY
 import csv, json, glob
