@@ -10,6 +10,7 @@
 #define RT_MAX_SCAN_BLOCKS (RT_MAX_CELLS / RT_SCAN_CHUNK)
 #define RT_WORK_LIST_COUNTS 32                     // first work[] word of the per-list tile counts (128 bytes after the head)
 #define RT_COST_SUM_PARTS 32u                       // partial sums of the cost estimate (power of two)
+#define RT_COUNTER_WORDS 88                        // 24 frame counters, 32 work-list words (64 x u32), 32 partial sums of the cost estimate
 #define RT_QUEUE_LISTS 16                          // tile lists the trace kernel serves in order (cost classes)
 
 // Grid description, resident in device memory: k_grid_setup writes the geometry, k_scan_apply writes n_refs.
@@ -120,7 +121,7 @@ struct RtBuildDev {
     float4* recs;                 // 3 * ref_cap
     float4* blk_bounds;           // 3 * (ref_cap / 64 + 2)
     uint32_t ref_cap;
-    unsigned long long* counters;
+    unsigned long long* counters; // RT_COUNTER_WORDS words the render kernels of the frame count in; the build clears them (may be NULL)
     unsigned long long* stamp;    // when not NULL, the first kernel of the build writes the 100 MHz real-time clock here (frame start)
     int32_t indexed;              // 1: recs holds one uint32 triangle index per reference instead of the 48-byte record
     int32_t sorted;               // 1: voxel lists in ascending triangle index (scatter, row sort, ranking; needs ref_tri, ref_cell,

@@ -449,7 +449,6 @@ struct FrameMem {
     size_t tile_cap = 0;                     // tiles the three lists above can hold (queue_lists: RT_QUEUE_LISTS times as many)
     uint32_t* unit_cost = nullptr;           // counting frames only: 112 words per tile
 };
-#define RT_COUNTER_WORDS 88                  // 24 frame counters, 32 work-list words (64 x u32), 32 partial sums of the cost estimate
 
 static FrameMem scene_mem(const rt_scene* s, const WorkSet& w, bool indexed = false) {
     FrameMem m;
@@ -809,7 +808,8 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
         }
     }
     const bool counting = s->count_work && m.unit_cost;
-    HIP_TRY(hipMemsetAsync(m.counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), side));
+    // frames with a grid build: the build has cleared the counters (k_scan_sums)
+    if (build == 0) HIP_TRY(hipMemsetAsync(m.counters, 0, RT_COUNTER_WORDS * sizeof(unsigned long long), side));
     if (counting) HIP_TRY(hipMemsetAsync(m.counters + 22, 0xff, sizeof(unsigned long long), side));   // slot of a minimum
     {
         // background everywhere first: black, no hit

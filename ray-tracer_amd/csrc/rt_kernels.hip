@@ -290,6 +290,9 @@ __global__ void __launch_bounds__(256) k_count_wide(RtBuildDev b) {
 // SCAN part 1: per-chunk totals. A chunk is RT_SCAN_CHUNK consecutive cells, one 256-thread block each.
 __global__ void k_scan_sums(RtBuildDev b) {
     __shared__ uint32_t wsum[4];
+    // the frame's counters and work-list words start at zero: cleared here, by a kernel the frame launches anyway before
+    // anything uses them, instead of by a memset of its own (one launch less in the frame's chain)
+    if (b.counters && blockIdx.x == 0 && threadIdx.x < RT_COUNTER_WORDS) b.counters[threadIdx.x] = 0ull;
     const int n_cells = b.grid->n_cells;
     uint32_t base = blockIdx.x * RT_SCAN_CHUNK;
     uint32_t s = 0;
