@@ -196,7 +196,10 @@ class Scene:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown: the module's globals may be gone already
+            pass
 
     # load_mesh(filename, triangle_list, format_has_vt, mesh_color, reflective=false, offset=(0,0,0))
     def load_mesh(self, filename, format_has_vt=True, mesh_color=(255, 0, 0), offset=(0, 0, 0)):

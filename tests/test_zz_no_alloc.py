@@ -52,3 +52,32 @@ def test_noalloc_entry_point_rejects_what_does_not_fit(rt):
     crowded = rt.Scene(); crowded.add_triangles(v9); crowded.upload()
     with pytest.raises(rt.RtError, match="references"):
         crowded.render_device_noalloc(rt.default_params(8, 8), d_u8=out.data_ptr())
+
+
+def test_noalloc_entry_point_under_graph_capture(rt):
+    """What the entry point is for: a frame captured into a HIP graph (no allocation may happen under capture) and replayed,
+    also after the outputs were overwritten, gives the frame of the plain call."""
+    import torch
+    s = rt.Scene(); s.load_mesh(SPOT); s.load_mesh(BLUB, True, (10, 200, 30), (1.5, 0, 0))
+    s.upload()
+    p = rt.default_params(640, 480)
+    w_rgb, w_u8, w_ids = _frame(rt, torch, s, p, False)
+    rgb = torch.full((480, 640, 3), -1.0, dtype=torch.float32, device="cuda")
+    u8 = torch.full((480, 640, 3), 9, dtype=torch.uint8, device="cuda")
+    ids = torch.full((480, 640), -9, dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        s.render_device_noalloc(p, d_rgb=rgb.data_ptr(), d_u8=u8.data_ptr(), d_ids=ids.data_ptr(), stream=st.cuda_stream)   # first call outside the capture
+        st.synchronize()
+        g.capture_begin()
+        s.render_device_noalloc(p, d_rgb=rgb.data_ptr(), d_u8=u8.data_ptr(), d_ids=ids.data_ptr(), stream=st.cuda_stream)
+        g.capture_end()
+    for _ in range(2):
+        rgb.fill_(-1.0); u8.fill_(9); ids.fill_(-9)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(ids.cpu().numpy(), w_ids)
+        assert np.array_equal(rgb.cpu().numpy().view(np.uint32), w_rgb.view(np.uint32))
+        assert np.array_equal(u8.cpu().numpy(), w_u8)
