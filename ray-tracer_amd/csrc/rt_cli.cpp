@@ -19,6 +19,7 @@ static void usage() {
             "usage: rt [--obj PATH [--no-vt] [--color R G B] [--offset X Y Z]]... [--size W H] [--out FILE]\n"
             "          [--cam X Y Z] [--target X Y Z] [--up X Y Z] [--fov DEG] [--full-walk] [--stats]\n"
             "          [--frames N [--in-flight D]]   (render the frame N times, D frames in flight, and print the frame rate)\n"
+            "          [--gpus G]   (the frame shared out over the first G GPUs in bands, gathered to GPU 0 with RCCL; with --frames: the rate)\n"
             "          [--parallel-shading [--light X Y Z] [--eps E] [--shadow-scale S] [--reflect-depth D]]\n"
             "          per mesh: [--scale N] [--material KD KS ALPHA KA KM REFLECTIVE]   (fast_trace of the Parallel tree)\n"
             "       with no --obj: spot_triangulated.obj and blub_triangulated.obj (+1.5 in x) from the working directory\n");
@@ -30,7 +31,7 @@ int main(int argc, char** argv) {
     std::vector<MeshArg> meshes;
     std::string out = "./test.ppm";
     bool stats = false;
-    int frames = 0, in_flight = 4;
+    int frames = 0, in_flight = 4, gpus = 0;
     auto need = [&](int i, int n) { if (i + n >= argc) { usage(); exit(2); } };
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -61,24 +62,78 @@ int main(int argc, char** argv) {
         else if (a == "--stats") stats = true;
         else if (a == "--frames") { need(i, 1); frames = atoi(argv[++i]); }
         else if (a == "--in-flight") { need(i, 1); in_flight = atoi(argv[++i]); }
+        else if (a == "--gpus") { need(i, 1); gpus = atoi(argv[++i]); }
         else { usage(); return 2; }
     }
     if (meshes.empty()) {
         meshes.push_back(MeshArg{"spot_triangulated.obj", 1, {255, 0, 0}, {0, 0, 0}, 1, {}, false});
         meshes.push_back(MeshArg{"blub_triangulated.obj", 1, {255, 0, 0}, {1.5f, 0, 0}, 1, {}, false});
     }
-    rt_scene* s = rt_scene_create();
-    for (auto& m : meshes) {
-        long long n;
-        if (m.has_mat || m.scale != 1) {
-            if (!m.has_mat) { m.mat.kd = 10; m.mat.ks = 10; m.mat.spec_alpha = 1.25f; m.mat.ka = 0.3f; m.mat.km = 0; m.mat.reflective = 0; }
-            for (int k = 0; k < 3; ++k) m.mat.base_color[k] = m.color[k];
-            n = rt_scene_add_obj_material(s, m.path.c_str(), m.has_vt, &m.mat, m.offset, m.scale);
-        } else {
-            n = rt_scene_add_obj(s, m.path.c_str(), m.has_vt, m.color, m.offset);
+    auto load_scene = [&]() -> rt_scene* {
+        rt_scene* sc = rt_scene_create();
+        for (auto& m : meshes) {
+            long long n;
+            if (m.has_mat || m.scale != 1) {
+                if (!m.has_mat) { m.mat.kd = 10; m.mat.ks = 10; m.mat.spec_alpha = 1.25f; m.mat.ka = 0.3f; m.mat.km = 0; m.mat.reflective = 0; }
+                for (int k = 0; k < 3; ++k) m.mat.base_color[k] = m.color[k];
+                n = rt_scene_add_obj_material(sc, m.path.c_str(), m.has_vt, &m.mat, m.offset, m.scale);
+            } else {
+                n = rt_scene_add_obj(sc, m.path.c_str(), m.has_vt, m.color, m.offset);
+            }
+            if (n < 0) { fprintf(stderr, "rt: %s\n", rt_last_error()); rt_scene_destroy(sc); return nullptr; }
         }
-        if (n < 0) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
+        return sc;
+    };
+    if (gpus > 0) {
+        // The frame on several GPUs of this process: every GPU holds the scene and renders the bands of its part, one RCCL
+        // gather brings them to the first GPU, which puts them in frame order.
+        if (gpus > 64) { usage(); return 2; }
+        auto fail = [&](const char* what) { fprintf(stderr, "rt: %s: %s\n", what, rt_last_error()); return 1; };
+        rt_comm* comm = nullptr;
+        if (rt_comm_create(gpus, nullptr, &comm)) return fail("rt_comm_create");
+        std::vector<rt_scene*> sc((size_t)gpus, nullptr);
+        std::vector<void*> d_part((size_t)gpus, nullptr);
+        p.part_count = gpus; p.part_index = 0;
+        const size_t part_bytes = (size_t)rt_part_rows(&p) * p.width * 3, frame_bytes = (size_t)p.width * p.height * 3;
+        void *d_stacked = nullptr, *d_frame = nullptr;
+        for (int r = 0; r < gpus; ++r) {
+            if (hipSetDevice(r) != hipSuccess) { fprintf(stderr, "rt: cannot select GPU %d\n", r); return 1; }
+            if (!(sc[r] = load_scene())) return 1;
+            if (rt_scene_upload(sc[r])) return fail("rt_scene_upload");
+            if (hipMalloc(&d_part[r], part_bytes) != hipSuccess) { fprintf(stderr, "rt: out of device memory\n"); return 1; }
+        }
+        (void)hipSetDevice(0);
+        if (hipMalloc(&d_stacked, part_bytes * gpus) != hipSuccess || hipMalloc(&d_frame, frame_bytes) != hipSuccess) { fprintf(stderr, "rt: out of device memory\n"); return 1; }
+        const int count = frames > 0 ? frames : 1;
+        double ms = 0;
+        for (int pass = 0; pass < (frames > 0 ? 2 : 1); ++pass) {        // with --frames the first pass warms up
+            const int n_pass = (frames > 0 && pass == 0) ? 3 : count;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < n_pass; ++k) {
+                for (int r = 0; r < gpus; ++r) {
+                    (void)hipSetDevice(r);
+                    rt_params q = p;
+                    q.part_index = r;
+                    if (rt_render_device(sc[r], &q, 1, nullptr, d_part[r], nullptr, nullptr)) return fail("rt_render_device");
+                }
+                if (rt_gather_bands(comm, &p, d_part.data(), d_stacked, d_frame, 3, nullptr)) return fail("rt_gather_bands");
+            }
+            for (int r = 0; r < gpus; ++r) { (void)hipSetDevice(r); if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "rt: device error\n"); return 1; } }
+            ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n_pass;
+        }
+        if (frames > 0) fprintf(stderr, "%d frames of %dx%d on %d GPUs: %.4f ms per frame\n", frames, p.width, p.height, gpus, ms);
+        (void)hipSetDevice(0);
+        std::vector<unsigned char> img(frame_bytes);
+        if (hipMemcpy(img.data(), d_frame, frame_bytes, hipMemcpyDeviceToHost) != hipSuccess || rt_write_ppm_u8(out.c_str(), img.data(), p.width, p.height)) {
+            fprintf(stderr, "rt: cannot write %s\n", out.c_str()); return 1;
+        }
+        (void)hipFree(d_stacked); (void)hipFree(d_frame);
+        for (int r = 0; r < gpus; ++r) { (void)hipSetDevice(r); (void)hipFree(d_part[r]); rt_scene_destroy(sc[r]); }
+        rt_comm_destroy(comm);
+        return 0;
     }
+    rt_scene* s = load_scene();
+    if (!s) return 1;
     if (frames > 0) {
         // a stream of frames: frame k on lane k % D, each with its own grid build and its own RGB8 buffer on the device
         void* lane[8] = {};

@@ -479,6 +479,20 @@ def test_command_line_program_renders_a_stream_of_frames(tmp_path):
     assert hashlib.md5((tmp_path / "test.ppm").read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
 
 
+def test_command_line_program_through_the_multi_gpu_path(tmp_path):
+    """--gpus 1: the frame rendered as parts, gathered with RCCL and put in frame order (the path a node with several GPUs
+    takes, here with one part); the image is the reference's."""
+    import hashlib, shutil, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "ray-tracer_amd", "rt")
+    shutil.copy(SPOT, tmp_path / "spot_triangulated.obj")
+    shutil.copy(BLUB, tmp_path / "blub_triangulated.obj")
+    r = subprocess.run([exe, "--gpus", "1", "--frames", "5"], cwd=tmp_path, timeout=100, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "on 1 GPUs" in r.stderr
+    assert hashlib.md5((tmp_path / "test.ppm").read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
+
+
 def test_unit_diagnostics_are_consistent(rt):
     """rt_scene_unit_costs after a counting frame: one record per work unit, and the per-unit numbers add up to the
     per-tile and per-frame ones (layout in include/rt_amd.h)."""
