@@ -1214,7 +1214,11 @@ static int write_ppm_impl(const char* path, const float* rgb, int32_t w, int32_t
     for (size_t i = 0; i < n; ++i) {
         float q = rgb[i] / 255;
         float m = (q < 1.f) ? q : 1.f;          // std::min(float(1), q): a NaN gives 1
-        b[i] = (uint8_t)(m * 255);
+        // (unsigned char)(float) of a negative value is undefined in C++; what the reference's x86 code does is convert to
+        // a 32-bit integer (out of range: 0x80000000) and keep the low byte
+        const float v = m * 255;
+        const int32_t iv = (v > -2147483648.f) ? (int32_t)v : INT32_MIN;
+        b[i] = (uint8_t)(uint32_t)iv;
     }
     return rt_write_ppm_u8(path, b.data(), w, h);
 }

@@ -929,9 +929,10 @@ __device__ __forceinline__ void write_pixel(const RtFrame& f, const RtOutputs& o
         if (o.rgb_f32) { o.rgb_f32[3 * pix] = cr; o.rgb_f32[3 * pix + 1] = cg; o.rgb_f32[3 * pix + 2] = cb; }
         if (o.rgb_u8) {
             // PPM quantisation, Serial/raytracer.cpp:181-183: (unsigned char)(min(1, c/255)*255); a NaN gives 255
-            o.rgb_u8[3 * pix] = (uint8_t)(min_std(1.f, cr / 255) * 255);
-            o.rgb_u8[3 * pix + 1] = (uint8_t)(min_std(1.f, cg / 255) * 255);
-            o.rgb_u8[3 * pix + 2] = (uint8_t)(min_std(1.f, cb / 255) * 255);
+            // through a 32-bit integer, low byte kept: what the reference's x86 code does with a negative value as well
+            o.rgb_u8[3 * pix] = (uint8_t)(uint32_t)(int32_t)(min_std(1.f, cr / 255) * 255);
+            o.rgb_u8[3 * pix + 1] = (uint8_t)(uint32_t)(int32_t)(min_std(1.f, cg / 255) * 255);
+            o.rgb_u8[3 * pix + 2] = (uint8_t)(uint32_t)(int32_t)(min_std(1.f, cb / 255) * 255);
         }
         if (o.hit_id) o.hit_id[pix] = id;
     }

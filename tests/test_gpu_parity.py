@@ -72,6 +72,18 @@ def test_u8_output_is_the_ppm_quantisation(rt, O, plane10):
     assert np.array_equal(u8, O.quantize(rgb))
 
 
+def test_u8_output_of_negative_colours(rt, O):
+    """A mesh colour with negative components gives negative pixel values. The reference's cast of a negative float to
+    unsigned char is undefined in C++; its x86 code converts to a 32-bit integer and keeps the low byte (-5.0 -> 251). The
+    kernel and the host writer do that explicitly, and agree with the oracle's compiled cast."""
+    s = rt.Scene(); s.load_mesh(SPOT, True, (-40.0, 90.0, -0.5))
+    rgb, u8, ids = s.render(rt.default_params(200, 150), want_u8=True)
+    assert (rgb[ids >= 0][:, 0] < -1).any()
+    want = (np.minimum(np.float32(1), rgb / np.float32(255)) * np.float32(255)).astype(np.int32).astype(np.uint8)      # through int32, low byte
+    assert np.array_equal(u8, want)
+    assert np.array_equal(u8, O.quantize(rgb))
+
+
 @pytest.mark.parametrize("W,H", [(1920, 1080), (1, 1), (7, 3), (65, 129)])
 def test_spot_sizes_against_oracle(rt, O, W, H):
     s = rt.Scene(); s.load_mesh(SPOT)
