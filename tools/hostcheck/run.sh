@@ -7,4 +7,4 @@ R=$(cd "$(dirname "$0")/../.." && pwd); O=${RT_HOSTCHECK_TMP:-/tmp}/rt_hostcheck
   -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer \
   $R/ray-tracer_amd/csrc/rt_kernels.hip $R/ray-tracer_amd/csrc/rt_host.cpp $R/ray-tracer_amd/csrc/rt_comm.cpp $R/tools/hostcheck/driver.cpp \
   -o $O -ldl
-ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 $O
+ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 $O
