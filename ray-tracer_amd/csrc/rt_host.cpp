@@ -11,8 +11,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
@@ -261,6 +263,63 @@ extern "C" int rt_scene_get_triangles(const rt_scene* s, float* v9) {
 
 static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
 
+// One stretch of the file, from the start of a line to the end of a line: the vertices it holds and its faces, every face
+// with the number of vertices of the stretch that precede it (a face may only name vertices read before it).
+struct ObjFace { int32_t idx[3]; uint32_t nv_before; uint32_t line; };
+struct ObjPart {
+    std::vector<float> verts;
+    std::vector<ObjFace> faces;
+    uint32_t lines = 0;
+    bool failed = false;              // out of memory inside the worker
+};
+
+static void parse_obj_part(char* p, char* const end, const double off[3], double scale, ObjPart& out) {
+    try {
+        while (p < end) {
+            char* nl = (char*)memchr(p, '\n', (size_t)(end - p));
+            char* le = nl ? nl : end;
+            ++out.lines;
+            char saved = *le;
+            *le = 0;   // strtod must not run into the next line (the byte belongs to this stretch, or is the buffer's terminator)
+            char* q = p;
+            while (q < le && is_ws(*q)) ++q;
+            char* t = q;
+            while (t < le && !is_ws(*t)) ++t;
+            if (t - q == 1 && *q == 'v') {
+                double c[3] = {0, 0, 0};
+                char* r = t;
+                for (int k = 0; k < 3; ++k) {
+                    char* e = nullptr;
+                    double d = strtod(r, &e);
+                    if (e == r) break;   // operator>> stores 0 and the stream stays failed
+                    c[k] = d;
+                    r = e;
+                }
+                out.verts.push_back((float)(scale * (c[0] + off[0])));      // times 1.0 is exact: the Serial loader's value
+                out.verts.push_back((float)(scale * (c[1] + off[1])));
+                out.verts.push_back((float)(scale * (c[2] + off[2])));
+            } else if (t - q == 1 && *q == 'f') {
+                ObjFace fc;
+                char* r = t;
+                for (int k = 0; k < 3; ++k) {
+                    while (r < le && is_ws(*r)) ++r;
+                    bool neg = false;
+                    if (r < le && (*r == '+' || *r == '-')) { neg = (*r == '-'); ++r; }
+                    long v = 0;
+                    while (r < le && *r >= '0' && *r <= '9') { v = v * 10 + (*r - '0'); if (v > 0x7fffffff) v = 0x7fffffff; ++r; }
+                    fc.idx[k] = (int32_t)(neg ? -v : v);
+                    while (r < le && !is_ws(*r)) ++r;   // "/vt" and anything else glued to the token
+                }
+                fc.nv_before = (uint32_t)(out.verts.size() / 3);
+                fc.line = out.lines;
+                out.faces.push_back(fc);
+            }
+            *le = saved;
+            p = nl ? nl + 1 : end;
+        }
+    } catch (...) { out.failed = true; }
+}
+
 static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, const rt_material* mat, const float offset[3], int32_t scale_i) {
     (void)format_has_vt;   // the texture index is parsed by the reference but never used by the path
     if (!s || !path || !mat || !offset) return set_err(RT_ERR_INVALID, "rt_scene_add_obj: bad argument");
@@ -279,67 +338,78 @@ static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, co
     if (read_err || got > (size_t)sz) return set_err(RT_ERR_IO, "%s: read error", path);
     buf[got] = 0;
 
-    std::vector<float> verts;
-    verts.reserve(1 << 16);
-    const uint32_t mesh = (uint32_t)(s->mesh_color.size() / 3);
-    const size_t tri_before = s->tri_mesh.size();
+    // The file is cut into stretches of whole lines that are parsed side by side (files of a few MB: one stretch); a face's
+    // indices are checked afterwards against the vertices read before it in file order, and the triangles are emitted in
+    // file order, so the result is that of reading the file line by line.
     const double off[3] = {(double)offset[0], (double)offset[1], (double)offset[2]};
-    char* p = buf.data();
-    char* const end = p + got;
-    int64_t line_no = 0;
-    while (p < end) {
-        char* nl = (char*)memchr(p, '\n', (size_t)(end - p));
-        char* le = nl ? nl : end;
-        ++line_no;
-        char saved = *le;
-        *le = 0;   // strtod must not run into the next line
-        char* q = p;
-        while (q < le && is_ws(*q)) ++q;
-        char* t = q;
-        while (t < le && !is_ws(*t)) ++t;
-        if (t - q == 1 && *q == 'v') {
-            double c[3] = {0, 0, 0};
-            char* r = t;
-            for (int k = 0; k < 3; ++k) {
-                char* e = nullptr;
-                double d = strtod(r, &e);
-                if (e == r) break;   // operator>> stores 0 and the stream stays failed
-                c[k] = d;
-                r = e;
-            }
-            verts.push_back((float)(scale * (c[0] + off[0])));      // times 1.0 is exact: the Serial loader's value
-            verts.push_back((float)(scale * (c[1] + off[1])));
-            verts.push_back((float)(scale * (c[2] + off[2])));
-        } else if (t - q == 1 && *q == 'f') {
-            long idx[3] = {0, 0, 0};
-            char* r = t;
-            for (int k = 0; k < 3; ++k) {
-                while (r < le && is_ws(*r)) ++r;
-                bool neg = false;
-                if (r < le && (*r == '+' || *r == '-')) { neg = (*r == '-'); ++r; }
-                long v = 0;
-                while (r < le && *r >= '0' && *r <= '9') { v = v * 10 + (*r - '0'); if (v > 0x7fffffff) v = 0x7fffffff; ++r; }
-                idx[k] = neg ? -v : v;
-                while (r < le && !is_ws(*r)) ++r;   // "/vt" and anything else glued to the token
-            }
-            const long nv = (long)(verts.size() / 3);
-            if (idx[0] < 1 || idx[1] < 1 || idx[2] < 1 || idx[0] > nv || idx[1] > nv || idx[2] > nv) {
-                s->tri.resize(tri_before * 9);
-                s->tri_mesh.resize(tri_before);
-                return set_err(RT_ERR_OBJ, "%s:%lld: face index outside 1..%ld", path, (long long)line_no, nv);
-            }
-            for (int k = 0; k < 3; ++k) {
-                const float* v = &verts[3 * (size_t)(idx[k] - 1)];
-                s->tri.push_back(v[0]); s->tri.push_back(v[1]); s->tri.push_back(v[2]);
-            }
-            s->tri_mesh.push_back(mesh);
+    int n_parts = 1;
+    if (got >= ((size_t)4 << 20)) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        n_parts = (int)(hw < 1 ? 1 : (hw > 16 ? 16 : hw));
+    }
+    if (const char* e = getenv("RT_OBJ_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_parts = v; }     // experiments and tests
+    std::vector<size_t> cut((size_t)n_parts + 1, got);
+    cut[0] = 0;
+    for (int k = 1; k < n_parts; ++k) {
+        size_t c = got / (size_t)n_parts * (size_t)k;
+        if (c < cut[k - 1]) c = cut[k - 1];
+        const char* nl = (const char*)memchr(buf.data() + c, '\n', got - c);
+        cut[k] = nl ? (size_t)(nl - buf.data()) + 1 : got;
+    }
+    std::vector<ObjPart> parts((size_t)n_parts);
+    if (n_parts == 1) {
+        parts[0].verts.reserve(1 << 16);
+        parse_obj_part(buf.data(), buf.data() + got, off, scale, parts[0]);
+    } else {
+        std::vector<std::thread> workers;
+        for (int k = 0; k < n_parts; ++k)
+            workers.emplace_back(parse_obj_part, buf.data() + cut[k], buf.data() + cut[k + 1], off, scale, std::ref(parts[k]));
+        for (std::thread& t : workers) t.join();
+    }
+    for (const ObjPart& pt : parts)
+        if (pt.failed) throw std::bad_alloc();
+    // vertices and lines before each stretch
+    std::vector<size_t> v_before((size_t)n_parts + 1, 0), l_before((size_t)n_parts + 1, 0), f_before((size_t)n_parts + 1, 0);
+    for (int k = 0; k < n_parts; ++k) {
+        v_before[k + 1] = v_before[k] + parts[k].verts.size() / 3;
+        l_before[k + 1] = l_before[k] + parts[k].lines;
+        f_before[k + 1] = f_before[k] + parts[k].faces.size();
+    }
+    if (s->tri_mesh.size() + f_before[n_parts] >= 0x7fffffffull) return set_err(RT_ERR_INVALID, "too many triangles");
+    // the first face in file order whose index lies outside the vertices read so far ends the call (the reference reads out of bounds)
+    for (int k = 0; k < n_parts; ++k)
+        for (const ObjFace& fc : parts[k].faces) {
+            const long nv = (long)(v_before[k] + fc.nv_before);
+            if (fc.idx[0] < 1 || fc.idx[1] < 1 || fc.idx[2] < 1 || fc.idx[0] > nv || fc.idx[1] > nv || fc.idx[2] > nv)
+                return set_err(RT_ERR_OBJ, "%s:%lld: face index outside 1..%ld", path, (long long)(l_before[k] + fc.line), nv);
         }
-        *le = saved;
-        p = nl ? nl + 1 : end;
+    const uint32_t mesh = (uint32_t)(s->mesh_color.size() / 3);
+    const size_t tri_before = s->tri_mesh.size(), n_new = f_before[n_parts];
+    s->tri.resize((tri_before + n_new) * 9);
+    s->tri_mesh.resize(tri_before + n_new, mesh);
+    // a vertex by its index in the file: the stretch that holds it, then its place there
+    auto emit_part = [&](int k) {
+        float* dst = s->tri.data() + (tri_before + f_before[k]) * 9;
+        for (const ObjFace& fc : parts[k].faces) {
+            for (int c = 0; c < 3; ++c) {
+                const size_t g = (size_t)(fc.idx[c] - 1);
+                int owner = k;                                     // vertices read before the face: this stretch or an earlier one
+                while (g < v_before[owner]) --owner;
+                const float* v = &parts[owner].verts[3 * (g - v_before[owner])];
+                dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+                dst += 3;
+            }
+        }
+    };
+    if (n_parts == 1) emit_part(0);
+    else {
+        std::vector<std::thread> workers;
+        for (int k = 0; k < n_parts; ++k) workers.emplace_back(emit_part, k);
+        for (std::thread& t : workers) t.join();
     }
     push_mesh(s, *mat);
     scene_touch(s);
-    return (int64_t)(s->tri_mesh.size() - tri_before);
+    return (int64_t)n_new;
 }
 
 static int64_t add_obj_guarded(rt_scene* s, const char* path, int format_has_vt, const rt_material* mat, const float offset[3], int32_t scale) {

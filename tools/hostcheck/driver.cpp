@@ -84,11 +84,72 @@ int main() {
             std::vector<float> v9((size_t)n * 9);
             CHECK(rt_scene_get_triangles(s, v9.data()) == RT_OK);
         }
+        // the same file read in several stretches side by side: same status, same triangles
+        {
+            const int threads = 2 + (int)(rng() % 6);
+            setenv("RT_OBJ_THREADS", std::to_string(threads).c_str(), 1);
+            rt_scene* s2 = rt_scene_create();
+            const long long n_par = rt_scene_add_obj(s2, path.c_str(), 1, col, off);
+            unsetenv("RT_OBJ_THREADS");
+            CHECK(n_par == n);
+            if (n > 0 && n_par == n) {
+                std::vector<float> a((size_t)n * 9), b((size_t)n * 9);
+                rt_scene_get_triangles(s, a.data()); rt_scene_get_triangles(s2, b.data());
+                CHECK(memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0);
+            }
+            rt_scene_destroy(s2);
+        }
         // a second mesh on top, with a material and a scale
         rt_material m; memset(&m, 0, sizeof(m)); m.kd = 1; m.base_color[0] = 9;
         const long long n2 = rt_scene_add_obj_material(s, path.c_str(), 0, &m, off, 3);
         CHECK(n2 == n || (n2 < 0 && n < 0));
         rt_scene_destroy(s);
+    }
+    // well-formed files with vertices and faces interleaved, some with one bad face: one stretch against several
+    {
+        long long valid = 0, invalid = 0;
+        for (int it = 0; it < 400; ++it) {
+            std::string text;
+            int nv = 0;
+            const int lines = 20 + (int)(rng() % 400);
+            const bool spoil = (rng() % 3) == 0;
+            const int spoil_at = (int)(rng() % lines);
+            for (int k = 0; k < lines; ++k) {
+                const unsigned r = (unsigned)(rng() % 10);
+                char tmp[160];
+                if (r < 5 || nv < 3) {
+                    snprintf(tmp, sizeof(tmp), "v %.6f %.6f %g\n", (double)(rng() % 2000) / 100.0 - 10.0, (double)(rng() % 2000) / 7.0, (double)(rng() % 1000) * 1e-3);
+                    ++nv;
+                } else if (r < 9) {
+                    int a = 1 + (int)(rng() % nv), b = 1 + (int)(rng() % nv), c = 1 + (int)(rng() % nv);
+                    if (spoil && k >= spoil_at && (rng() % 4) == 0) c = nv + 1 + (int)(rng() % 3);       // names a vertex that comes later, or none
+                    if (rng() & 1) snprintf(tmp, sizeof(tmp), "f %d/1 %d/1 %d/1\n", a, b, c); else snprintf(tmp, sizeof(tmp), "f %d %d %d\n", a, b, c);
+                } else {
+                    snprintf(tmp, sizeof(tmp), "vt 0 0\n# %d\n\n", k);
+                }
+                text += tmp;
+            }
+            write_file(path, text);
+            rt_scene* s1 = rt_scene_create();
+            unsetenv("RT_OBJ_THREADS");
+            const long long n1 = rt_scene_add_obj(s1, path.c_str(), 1, col, off);
+            const std::string err1 = n1 < 0 ? rt_last_error() : "";
+            setenv("RT_OBJ_THREADS", std::to_string(2 + (int)(rng() % 9)).c_str(), 1);
+            rt_scene* s2 = rt_scene_create();
+            const long long n2 = rt_scene_add_obj(s2, path.c_str(), 1, col, off);
+            const std::string err2 = n2 < 0 ? rt_last_error() : "";
+            unsetenv("RT_OBJ_THREADS");
+            CHECK(n1 == n2);
+            CHECK(err1 == err2);                                       // the same line and vertex count in the message
+            if (n1 > 0 && n1 == n2) {
+                std::vector<float> a((size_t)n1 * 9), b((size_t)n1 * 9);
+                rt_scene_get_triangles(s1, a.data()); rt_scene_get_triangles(s2, b.data());
+                CHECK(memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0);
+            }
+            if (n1 >= 0) ++valid; else ++invalid;
+            rt_scene_destroy(s1); rt_scene_destroy(s2);
+        }
+        CHECK(valid > 100 && invalid > 30);
     }
     // in-memory meshes
     {
