@@ -1506,6 +1506,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         if (at_voxel) { cbeg = s.cell_start[w.cell]; cend = s.cell_start[w.cell + 1]; }
         const long long t1 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (COUNT) { wc.rounds += 1; wc.cyc_step += (uint32_t)(t1 - t0); if (alive) wc.tests += cend - cbeg; }
+        // most rounds of a unit only move a few rays on through empty space: nothing to cull or to test
+        if (!un) continue;
         // ---- CULL (crowded voxels only): every ray against the boxes of the 64-record runs of ITS voxel, lane = ray.
         // A voxel's records are visited in runs of 64. Crowded voxels use runs aligned to multiples of 64 in the record
         // array, which is what the per-run boxes describe; a run is skipped for a ray when the ray's whole line misses
