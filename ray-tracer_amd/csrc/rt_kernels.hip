@@ -1460,7 +1460,9 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 // rounded, so the nearest hit is the plain minimum (ties: earlier voxel, then lower index) and a shadow query is true only
 // for passing triangles beyond eps. With RULE 1 `td` carries the nearest distance; st.t is kept at td rounded up to float
 // for the early-exit comparison (never stops a ray the exact comparison would not stop), st.id is the nearest triangle.
-template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT, bool OWN, int RULE = 0>
+// IDX says what the voxel lists hold, where the kernel is built for one answer: 0 records, 1 triangle indices, 2 either
+// (RtSceneDev::indexed decides at run time).
+template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT, bool OWN, int RULE = 0, int IDX = 2>
 __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* bitmap, int lane, bool active, float ox,
                                           float oy, float oz, float dx, float dy, float dz, float mint, bool use_eps, float eps,
                                           bool early, float slack, uint32_t cull_min, int ray_lanes, Nearest& st, WalkCount& wc,
@@ -1738,11 +1740,15 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         };
         auto load_item = [&](const Item& it, float4& r0, float4& r1, float4& r2) {
             const uint32_t p = it.base + lane;
-            const float4* r = RT_REC_PTR(s, ((p >= it.b && p < it.e) ? p : it.b));
+            const uint32_t q = (p >= it.b && p < it.e) ? p : it.b;
+            const float4* r = IDX == 0 ? s.recs + 3ull * q
+                            : IDX == 1 ? s.tri_rec + 3ull * reinterpret_cast<const uint32_t*>(s.recs)[q] : RT_REC_PTR(s, q);
             r0 = r[0]; r1 = r[1]; r2 = r[2];
         };
         // Two runs are kept in flight: the records of item i+2 are requested before item i is tested, so a load has the
-        // time of two items' tests to arrive (slots A and B take turns).
+        // time of two items' tests to arrive (slots A and B take turns). Every load below is unconditional -- a slot
+        // without a next item loads the item it has again -- because loads behind a branch make the compiler merge the
+        // two slots into one and wait for all outstanding loads before each test.
         auto process = [&](const Item& cur, const TriRec& t) {
             const uint32_t base = cur.base, e = cur.e;
             const bool have = base + lane >= cur.b && base + lane < e;
@@ -1841,24 +1847,27 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         Item itA, itB;
         float4 a0, a1, a2, b0, b1, b2;
         bool hA = next_item(itA);
-        if (hA) load_item(itA, a0, a1, a2);
-        bool hB = hA && next_item(itB);
-        if (hB) load_item(itB, b0, b1, b2);
-        while (hA) {
-            {
-                const TriRec t = unpack_rec(a0, a1, a2);
-                const Item cur = itA;
-                hA = hB && next_item(itA);
-                if (hA) load_item(itA, a0, a1, a2);
-                process(cur, t);
-            }
-            if (!hB) break;
-            {
-                const TriRec t = unpack_rec(b0, b1, b2);
-                const Item cur = itB;
-                hB = hA && next_item(itB);
-                if (hB) load_item(itB, b0, b1, b2);
-                process(cur, t);
+        if (hA) {
+            load_item(itA, a0, a1, a2);
+            bool hB = next_item(itB);
+            load_item(hB ? itB : itA, b0, b1, b2);
+            for (;;) {
+                {
+                    const TriRec t = unpack_rec(a0, a1, a2);
+                    const Item cur = itA;
+                    hA = hB && next_item(itA);
+                    load_item(hA ? itA : cur, a0, a1, a2);
+                    process(cur, t);
+                }
+                if (!hB) break;
+                {
+                    const TriRec t = unpack_rec(b0, b1, b2);
+                    const Item cur = itB;
+                    hB = hA && next_item(itB);
+                    load_item(hB ? itB : cur, b0, b1, b2);
+                    process(cur, t);
+                }
+                if (!hA) break;
             }
         }
         if (!ANY_HIT && RULE == 0) vb_apply(vb, st);
@@ -1981,7 +1990,7 @@ __device__ __forceinline__ void trace_unit_parallel(const RtSceneDev& s, const R
     out_r = Rr; out_g = Rg; out_b = Rb;
 }
 
-template <bool COUNT, bool OWN, int MODE = 0>
+template <bool COUNT, bool OWN, int MODE = 0, int IDX = 2>
 __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArgs args_in_kernarg_segment) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -2066,7 +2075,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
         WalkCount wp = {}, ws = {};
         const long long t_start = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const unsigned long long rt_start = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        const bool hit_any = wave_walk<false, true, COUNT, OWN>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
+        const bool hit_any = wave_walk<false, true, COUNT, OWN, 0, IDX>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
                                                        sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, per_unit, st, wp);
         float colr = 0.f, colg = 0.f, colb = 0.f;
         float poix = 0.f, poiy = 0.f, poiz = 0.f, sx = 0.f, sy = 0.f, sz = 1.f;
@@ -2106,7 +2115,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArg
             sx = -(sh.light[0] - poix); sy = -(sh.light[1] - poiy); sz = -(sh.light[2] - poiz);
             normalize3(sx, sy, sz);
         }
-        const bool shadowed = wave_walk<true, false, COUNT, OWN>(s, bitmap, lane, hit, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
+        const bool shadowed = wave_walk<true, false, COUNT, OWN, 0, IDX>(s, bitmap, lane, hit, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
                                                             true, 0.f, (uint32_t)f.cull_min, per_unit, st, ws);
         if (hit) {
             if (shadowed) { cr = cr * sh.shadow_scale; cg = cg * sh.shadow_scale; cb = cb * sh.shadow_scale; }
@@ -2230,7 +2239,8 @@ hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, Rt
         else k_trace<true, false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     } else {
         if (f.own_path) k_trace<false, true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
-        else k_trace<false, false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+        else if (s.indexed) k_trace<false, false, 0, 1><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+        else k_trace<false, false, 0, 0><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     }
     return hipGetLastError();
 }
