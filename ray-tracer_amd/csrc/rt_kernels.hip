@@ -1847,7 +1847,50 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         Item itA, itB;
         float4 a0, a1, a2, b0, b1, b2;
         bool hA = next_item(itA);
-        if (hA) {
+        if (IDX == 1 && hA) {
+            // Lists of triangle indices: a third stage in front. The indices of item i+3 are requested a turn before the
+            // records of that item, so the gather never waits for an index load it has just issued. P is the item
+            // whose indices are on their way; once the items run out it keeps naming the last one.
+            auto load_idx = [&](const Item& it) -> uint32_t {
+                const uint32_t p = it.base + lane;
+                return reinterpret_cast<const uint32_t*>(s.recs)[(p >= it.b && p < it.e) ? p : it.b];
+            };
+            auto gather = [&](uint32_t idx, float4& r0, float4& r1, float4& r2) {
+                const float4* r = s.tri_rec + 3ull * idx;
+                r0 = r[0]; r1 = r[1]; r2 = r[2];
+            };
+            gather(load_idx(itA), a0, a1, a2);
+            itB = itA;
+            bool hB = next_item(itB);
+            gather(load_idx(itB), b0, b1, b2);
+            Item P = itB;
+            bool hP = hB && next_item(P);
+            uint32_t idxP = load_idx(P);
+            for (;;) {
+                {
+                    const TriRec t = unpack_rec(a0, a1, a2);
+                    const Item cur = itA;
+                    Item N = P;
+                    const bool hN = hP && next_item(N);
+                    const uint32_t idxN = load_idx(N);
+                    gather(idxP, a0, a1, a2);
+                    itA = P; hA = hP; P = N; hP = hN; idxP = idxN;
+                    process(cur, t);
+                }
+                if (!hB) break;
+                {
+                    const TriRec t = unpack_rec(b0, b1, b2);
+                    const Item cur = itB;
+                    Item N = P;
+                    const bool hN = hP && next_item(N);
+                    const uint32_t idxN = load_idx(N);
+                    gather(idxP, b0, b1, b2);
+                    itB = P; hB = hP; P = N; hP = hN; idxP = idxN;
+                    process(cur, t);
+                }
+                if (!hA) break;
+            }
+        } else if (hA) {
             load_item(itA, a0, a1, a2);
             bool hB = next_item(itB);
             load_item(hB ? itB : itA, b0, b1, b2);
