@@ -2034,7 +2034,11 @@ __device__ __forceinline__ void trace_unit_parallel(const RtSceneDev& s, const R
 }
 
 template <bool COUNT, bool OWN, int MODE = 0, int IDX = 2>
-__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, 4) k_trace(RtTraceArgs args_in_kernarg_segment) {
+// Four blocks per CU (128 VGPRs, a few of them spilled) for the streamed path of crowded grids; three (144 VGPRs, nothing
+// spilled) for the variants that also hold the small-voxel loop, whose frames are bound by the longest chain of one wavefront
+// rather than by the number of wavefronts (measured: 1080p frame of a 5.8 k triangle mesh 0.176 -> 0.166 ms; the streamed
+// path at three blocks is 4-11 % slower).
+__global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(RtTraceArgs args_in_kernarg_segment) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x & 63;
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
@@ -2244,7 +2248,7 @@ static int trace_blocks(const RtFrame& f, const RtRenderWork& wk) {
     const int tiles_x = (f.width + RT_TILE - 1) / RT_TILE;
     const int tiles_y = (f.out_rows + RT_TILE - 1) / RT_TILE;
     const int tiles = tiles_x * tiles_y;
-    int blocks = wk.n_cu * wk.blocks_per_cu;
+    int blocks = wk.n_cu * (f.own_path && wk.blocks_per_cu > 3 ? 3 : wk.blocks_per_cu);      // k_trace's launch bounds
     const int max_useful = (tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK;
     return blocks > max_useful ? max_useful : blocks;
 }
