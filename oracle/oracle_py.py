@@ -105,7 +105,10 @@ class OracleScene:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the module globals may be gone already
+            pass
 
     def add_obj(self, path, has_vt=True, color=(255, 0, 0), offset=(0, 0, 0)):
         return lib().rto_scene_add_obj(self.h, os.fsencode(path), int(has_vt), _f3(color), _f3(offset))

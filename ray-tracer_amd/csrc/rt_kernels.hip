@@ -6,6 +6,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <type_traits>
 
 #include <mutex>
 
@@ -668,20 +669,49 @@ __global__ void __launch_bounds__(256) k_order_emit(RtBuildDev b) {
 
 __device__ __forceinline__ float bcast_f32(float v, int src_lane);
 
-// Wavefront reductions without LDS traffic: four steps inside every row of 16 lanes on the data-parallel-primitive path
-// of the vector ALU (lane pairs 1 apart, 2 apart, mirrored in 8, mirrored in 16), then the four row results are read
-// through scalar registers. The result is the same in every lane.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+// Wavefront reductions without LDS traffic, all on the data-parallel-primitive path of the vector ALU: four steps inside
+// every row of 16 lanes (lane pairs 1 apart, 2 apart, mirrored in 8, mirrored in 16), then the last lane of row 0 goes to
+// row 1 and that of row 2 to row 3, then the last lane of row 1 to rows 2 and 3. The result, ((r0 . r1) . (r2 . r3)) of the
+// four row results, stands in lanes 48..63 only.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    auto from = [](float x, auto ctrl, auto rows) {       // rows a step does not write add zero
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xf, false));
+    };
+    using std::integral_constant;
+    v += from(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});        // quad_perm [1,0,3,2]
+    v += from(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});        // quad_perm [2,3,0,1]
+    v += from(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});       // row_half_mirror
+    v += from(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});       // row_mirror
+    v += from(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});       // row_bcast:15 into rows 1 and 3
+    return v + from(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}); // row_bcast:31 into rows 2 and 3
 }
-template <typename Op>
-__device__ __forceinline__ float wave_reduce_f32(float v, Op op) {
-    v = op(v, dpp_f32<0xB1>(v));        // quad_perm [1,0,3,2]
-    v = op(v, dpp_f32<0x4E>(v));        // quad_perm [2,3,0,1]
-    v = op(v, dpp_f32<0x141>(v));       // row_half_mirror
-    v = op(v, dpp_f32<0x140>(v));       // row_mirror
-    return op(op(bcast_f32(v, 0), bcast_f32(v, 16)), op(bcast_f32(v, 32), bcast_f32(v, 48)));
+// The same six steps for minima and maxima, written out: fminf() on a value the compiler cannot see through (a lane
+// permutation) costs a canonicalising instruction per operand and the permutation is not folded into it, four
+// instructions a step instead of one. The operands here are never NaN (they come out of fminf/fmaxf against an infinity).
+// A permuting instruction must not read a register the two instructions before it wrote; the steps of several
+// independent reductions are interleaved for that, with a one-cycle filler where there are only two.
+#define RT_DPP_STEP3(op, a, b, c, ctrl) \
+    "v_" op "_f32_dpp " a ", " a ", " a " " ctrl "\n v_" op "_f32_dpp " b ", " b ", " b " " ctrl "\n v_" op "_f32_dpp " c ", " c ", " c " " ctrl "\n"
+#define RT_DPP_ALL_STEPS3(op, a, b, c) \
+    "s_nop 1\n" \
+    RT_DPP_STEP3(op, a, b, c, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") \
+    RT_DPP_STEP3(op, a, b, c, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") \
+    RT_DPP_STEP3(op, a, b, c, "row_half_mirror row_mask:0xf bank_mask:0xf") \
+    RT_DPP_STEP3(op, a, b, c, "row_mirror row_mask:0xf bank_mask:0xf") \
+    RT_DPP_STEP3(op, a, b, c, "row_bcast:15 row_mask:0xa bank_mask:0xf") \
+    RT_DPP_STEP3(op, a, b, c, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+__device__ __forceinline__ void wave_min3_f32(float& a, float& b, float& c) { asm(RT_DPP_ALL_STEPS3("min", "%0", "%1", "%2") : "+v"(a), "+v"(b), "+v"(c)); }
+__device__ __forceinline__ void wave_max3_f32(float& a, float& b, float& c) { asm(RT_DPP_ALL_STEPS3("max", "%0", "%1", "%2") : "+v"(a), "+v"(b), "+v"(c)); }
+#define RT_DPP_STEP_MINMAX(lo, hi, ctrl) "v_min_f32_dpp " lo ", " lo ", " lo " " ctrl "\n v_max_f32_dpp " hi ", " hi ", " hi " " ctrl "\n s_nop 0\n"
+__device__ __forceinline__ void wave_min_max_f32(float& lo, float& hi) {
+    asm("s_nop 1\n"
+        RT_DPP_STEP_MINMAX("%0", "%1", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+        RT_DPP_STEP_MINMAX("%0", "%1", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        RT_DPP_STEP_MINMAX("%0", "%1", "row_half_mirror row_mask:0xf bank_mask:0xf")
+        RT_DPP_STEP_MINMAX("%0", "%1", "row_mirror row_mask:0xf bank_mask:0xf")
+        RT_DPP_STEP_MINMAX("%0", "%1", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+        RT_DPP_STEP_MINMAX("%0", "%1", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(lo), "+v"(hi));
 }
 
 // BLOCK BOUNDS of every aligned run of 64 records: the axis-aligned box of its triangles (lo.xyz + largest absolute
@@ -724,15 +754,13 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
             const float fx = bcast_f32(nx, 0), fy = bcast_f32(ny, 0), fz = bcast_f32(nz, 0);
             if (nx * fx + ny * fy + nz * fz < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
         }
-        auto f_min = [](float a, float c) { return fminf(a, c); };
-        auto f_max = [](float a, float c) { return fmaxf(a, c); };
-        auto f_add = [](float a, float c) { return a + c; };
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { lo[a] = wave_reduce_f32(lo[a], f_min); hi[a] = wave_reduce_f32(hi[a], f_max); }
-        nx = wave_reduce_f32(nx, f_add); ny = wave_reduce_f32(ny, f_add); nz = wave_reduce_f32(nz, f_add);
+        wave_min3_f32(lo[0], lo[1], lo[2]);
+        wave_max3_f32(hi[0], hi[1], hi[2]);
+        nx = bcast_f32(wave_sum_f32(nx), 63); ny = bcast_f32(wave_sum_f32(ny), 63); nz = bcast_f32(wave_sum_f32(nz), 63);
         {
             const float len = sqrtf(nx * nx + ny * ny + nz * nz);
-            if (len > 1e-30f && len < 1e30f) { nx /= len; ny /= len; nz /= len; } else { nx = 0.f; ny = 0.f; nz = 0.f; }
+            // one division: any vector near unit length will do, the slab's two distances below are measured along it
+            if (len > 1e-30f && len < 1e30f) { const float inv = 1.f / len; nx *= inv; ny *= inv; nz *= inv; } else { nx = 0.f; ny = 0.f; nz = 0.f; }
         }
         float dmin = INFINITY, dmax = -INFINITY;
         if (have) {
@@ -742,8 +770,8 @@ __global__ void __launch_bounds__(256) k_block_bounds(RtBuildDev b) {
                 dmin = fminf(dmin, d); dmax = fmaxf(dmax, d);
             }
         }
-        dmin = wave_reduce_f32(dmin, f_min); dmax = wave_reduce_f32(dmax, f_max);
-        if (lane == 0) {
+        wave_min_max_f32(dmin, dmax);
+        if (lane == 63) {          // the reductions end in the last row
             float m = 0.f;
 #pragma unroll
             for (int a = 0; a < 3; ++a) m = fmaxf(m, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
