@@ -6,7 +6,6 @@
 
 #include <limits.h>
 #include <math.h>
-#include <type_traits>
 
 #include <mutex>
 
@@ -673,17 +672,17 @@ __device__ __forceinline__ float bcast_f32(float v, int src_lane);
 // every row of 16 lanes (lane pairs 1 apart, 2 apart, mirrored in 8, mirrored in 16), then the last lane of row 0 goes to
 // row 1 and that of row 2 to row 3, then the last lane of row 1 to rows 2 and 3. The result, ((r0 . r1) . (r2 . r3)) of the
 // four row results, stands in lanes 48..63 only.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_or_zero(float v) {          // rows a step does not write read zero
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum_f32(float v) {
-    auto from = [](float x, auto ctrl, auto rows) {       // rows a step does not write add zero
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xf, false));
-    };
-    using std::integral_constant;
-    v += from(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});        // quad_perm [1,0,3,2]
-    v += from(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});        // quad_perm [2,3,0,1]
-    v += from(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});       // row_half_mirror
-    v += from(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});       // row_mirror
-    v += from(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});       // row_bcast:15 into rows 1 and 3
-    return v + from(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}); // row_bcast:31 into rows 2 and 3
+    v += dpp_or_zero<0xB1, 0xf>(v);         // quad_perm [1,0,3,2]
+    v += dpp_or_zero<0x4E, 0xf>(v);         // quad_perm [2,3,0,1]
+    v += dpp_or_zero<0x141, 0xf>(v);        // row_half_mirror
+    v += dpp_or_zero<0x140, 0xf>(v);        // row_mirror
+    v += dpp_or_zero<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    return v + dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
 }
 // The same six steps for minima and maxima, written out: fminf() on a value the compiler cannot see through (a lane
 // permutation) costs a canonicalising instruction per operand and the permutation is not folded into it, four
@@ -1074,26 +1073,33 @@ __device__ __forceinline__ void dda_setup(Dda& w, const GridU& g, float ox, floa
 
 // One step of the walk loop, Serial/grid.h:216-227, plus the early-exit rule. Returns false when the ray is done.
 // stepAxis comes from the 3-bit compare table {2,1,2,1,2,2,0,0}: axis 0 iff next0 < next1 and next0 < next2,
-// axis 1 iff not (next0 < next1) and next1 < next2, else axis 2. Written without branches on the axis.
+// axis 1 iff not (next0 < next1) and next1 < next2, else axis 2 (NaNs compare false in both forms). Written without
+// branches on the axis.
 __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t, float slack, float* crossed_t = nullptr) {
     // The optimiser has to treat the state as register values: without this it rewrites the selects below as one load
     // from a selected address, which pins the whole state in scratch memory. (In place: no copies are made.)
     asm("" : "+v"(w.next0), "+v"(w.next1), "+v"(w.next2), "+v"(w.delta0), "+v"(w.delta1), "+v"(w.delta2));
     asm("" : "+v"(w.left0), "+v"(w.left1), "+v"(w.left2), "+v"(w.cstep0), "+v"(w.cstep1), "+v"(w.cstep2));
     const float n0 = w.next0, n1 = w.next1, n2 = w.next2;
-    const bool c01 = n0 < n1, c02 = n0 < n2, c12 = n1 < n2;
-    const bool is0 = c01 && c02;
-    const bool is1 = !c01 && c12;
-    const bool is01 = is0 || is1;                   // else axis 2
-    const float nx_t = is0 ? n0 : (is1 ? n1 : n2);
-    const int lf = is0 ? w.left0 : (is1 ? w.left1 : w.left2);
+    // two levels: the nearer of axes 0 and 1 (axis 1 on a tie), then that one against axis 2 (axis 2 on a tie); the same
+    // choice as the table's, with one compare less and lane masks that combine in scalar registers
+    const bool c01 = n0 < n1;
+    const float na = c01 ? n0 : n1;
+    const bool is01 = na < n2;                      // else axis 2
+    const bool is0 = is01 && c01;
+    const bool is1 = is01 && !c01;
+    const float nx_t = is01 ? na : n2;
+    const int la = c01 ? w.left0 : w.left1;
+    const int lf = is01 ? la : w.left2;
     // the ray is done when it has a hit nearer than the next voxel (early exit) or stands in the last voxel of the
     // axis it would leave through (Pos[stepAxis] == Out[stepAxis]); one branch for both
     const float lim = best_t + fabsf(best_t) * slack;
     const bool go = !((early_hit && lim < nx_t) || lf == 0);
     if (go) {
-        const float dl = is0 ? w.delta0 : (is1 ? w.delta1 : w.delta2);
-        const int cs = is0 ? w.cstep0 : (is1 ? w.cstep1 : w.cstep2);
+        const float da = c01 ? w.delta0 : w.delta1;
+        const float dl = is01 ? da : w.delta2;
+        const int ca = c01 ? w.cstep0 : w.cstep1;
+        const int cs = is01 ? ca : w.cstep2;
         if (crossed_t) *crossed_t = nx_t;
         const float nn = nx_t + dl;
         w.next0 = is0 ? nn : n0;
