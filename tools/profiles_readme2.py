@@ -28,7 +28,7 @@ a = s.index(t2, s.index("One frame at a time (")) + len(t2); b = s.index("\nIn t
 s = s[:a] + r2 + s[b:]
 d = line("profiles/r02_final_default_bench_with_cpu.json")
 tr = json.load(open("profiles/traffic.json"))
-a = s.index("Plain runs without the profiler")
+a = s.index("Plain run without the profiler") if "Plain run without the profiler" in s else s.index("Plain runs without the profiler")
 s = s[:a] + ("Plain run without the profiler (`r02_final_default_bench_with_cpu.json`): stand-in %.3f ms per frame (%.1f Grays/s) with four frames in\n"
              "flight, %.3f ms one at a time (build %.3f + trace %.3f), %.3f ms with the copy to pinned host memory, close camera %.2f ms; parity of the\n"
              "whole frame against the oracle: %d id mismatch(es), %d colour(s) off by more than 1/255.\n\n"
