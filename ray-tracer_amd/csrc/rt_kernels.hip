@@ -1924,16 +1924,19 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 }
                 if (!hA) break;
             }
-        } else if (hA) {
+        } else if (OWN && hA) {
+            // kernel variants for sparse grids, where few voxels are streamed at all: two sets, the smaller code
+            // (measured: the three-set loop below costs these frames 2-7 %)
             load_item(itA, a0, a1, a2);
+            itB = itA;
             bool hB = next_item(itB);
-            load_item(hB ? itB : itA, b0, b1, b2);
+            load_item(itB, b0, b1, b2);
             for (;;) {
                 {
                     const TriRec t = unpack_rec(a0, a1, a2);
                     const Item cur = itA;
                     hA = hB && next_item(itA);
-                    load_item(hA ? itA : cur, a0, a1, a2);
+                    load_item(itA, a0, a1, a2);
                     process(cur, t);
                 }
                 if (!hB) break;
@@ -1941,10 +1944,40 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     const TriRec t = unpack_rec(b0, b1, b2);
                     const Item cur = itB;
                     hB = hA && next_item(itB);
-                    load_item(hB ? itB : cur, b0, b1, b2);
+                    load_item(itB, b0, b1, b2);
                     process(cur, t);
                 }
                 if (!hA) break;
+            }
+        } else if (hA) {
+            // Three register sets take turns: an item is tested straight out of the registers its records arrived in,
+            // and only then is the set given to the item three places on, so nothing is copied aside and the loads of
+            // the next two items are in flight during every test. An item is generated after the test before it, when
+            // the rays that test has finished (shadow query) are known.
+            Item itC;
+            float4 c0, c1, c2;
+            bool more = true;
+            auto gen = [&](Item& it) -> bool { if (more) more = next_item(it); return more; };   // `it` is left alone at the end
+            load_item(itA, a0, a1, a2);
+            itB = itA;
+            bool hB = gen(itB);
+            load_item(itB, b0, b1, b2);
+            itC = itA;
+            bool hC = gen(itC);
+            load_item(itC, c0, c1, c2);
+            for (;;) {
+                process(itA, unpack_rec(a0, a1, a2));
+                if (!hB) break;
+                hA = gen(itA);
+                load_item(itA, a0, a1, a2);
+                process(itB, unpack_rec(b0, b1, b2));
+                if (!hC) break;
+                hB = gen(itB);
+                load_item(itB, b0, b1, b2);
+                process(itC, unpack_rec(c0, c1, c2));
+                if (!hA) break;
+                hC = gen(itC);
+                load_item(itC, c0, c1, c2);
             }
         }
         if (!ANY_HIT && RULE == 0) vb_apply(vb, st);
