@@ -1884,7 +1884,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         if (IDX == 1 && hA) {
             // Lists of triangle indices: a third stage in front. The indices of item i+3 are requested a turn before the
             // records of that item, so the gather never waits for an index load it has just issued. P is the item
-            // whose indices are on their way; once the items run out it keeps naming the last one.
+            // whose indices are on their way; once the items run out it keeps naming the last one. Two register sets
+            // here: with three in rotation (as below) a rank's share of a frame was 4-6 % slower.
             auto load_idx = [&](const Item& it) -> uint32_t {
                 const uint32_t p = it.base + lane;
                 return reinterpret_cast<const uint32_t*>(s.recs)[(p >= it.b && p < it.e) ? p : it.b];
