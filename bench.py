@@ -226,6 +226,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Two side measurements first (untimed by the driver; they also bring the GPU to its working clocks before the timed
+    # region: with 5 warm-up frames only, the same 20 timed frames are 5 % slower).
+    # (1) the frame alone on the GPU in the benchmarked configuration: a few frames one after the other on one lane
+    ms_render_alone = ms_build_alone = None
+    if n_lanes > 1:
+        n_alone = max(3, min(args.steps, 10))
+        for _ in range(n_alone):
+            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
+        torch.cuda.synchronize()
+        st_a = [scene.stats_at(i) for i in range(n_alone - 1)]
+        ms_render_alone = float(np.mean([x["ms_render"] for x in st_a]))
+        ms_build_alone = float(np.mean([x["ms_build"] for x in st_a]))
+    # (2) frame time when latency is what counts: the scene set up for one frame at a time (one working set; the trace kernel
+    # then takes the whole GPU and large meshes prepare their work list beside the grid build), frames issued back to back
+    # on one stream
+    one_at_a_time = None
+    if world == 1:
+        scene.set_frames_in_flight(1)
+        n_one = max(4, min(args.steps, 20))
+        for _ in range(2):
+            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_one):
+            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
+        torch.cuda.synchronize()
+        dt_one = (time.perf_counter() - t1) / n_one
+        st_o = [scene.stats_at(i) for i in range(n_one)]
+        one_at_a_time = {"ms_per_frame": round(dt_one * 1e3, 4), "frames": n_one,
+                         "build": round(float(np.mean([x["ms_build"] for x in st_o])), 4), "render": round(float(np.mean([x["ms_render"] for x in st_o])), 4)}
+        scene.set_frames_in_flight(depth)
+        for k in range(n_lanes):          # the working sets of the lanes exist again before anything is timed
+            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[k].data_ptr(), stream=lane_handles[k])
+        torch.cuda.synchronize()
+
     for k in range(args.warmup):
         step(k)
     sync_all()
@@ -248,36 +283,10 @@ def main():
     ms_build = float(np.mean([x["ms_build"] for x in st]))
     hits_local = st[0]["hits"]
     rays_local = st[0]["primary_rays"] + hits_local
-    # the same frame alone on the GPU: a few frames one after the other on one lane (untimed by the driver)
-    ms_render_alone, ms_build_alone = ms_render, ms_build
-    if n_lanes > 1:
-        n_alone = max(3, min(args.steps, 10))
-        for _ in range(n_alone):
-            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
-        torch.cuda.synchronize()
-        st_a = [scene.stats_at(i) for i in range(n_alone - 1)]
-        ms_render_alone = float(np.mean([x["ms_render"] for x in st_a]))
-        ms_build_alone = float(np.mean([x["ms_build"] for x in st_a]))
-    # Frame time when latency is what counts: the scene set up for one frame at a time (one working set; the trace kernel
-    # then takes the whole GPU and large meshes prepare their work list beside the grid build), frames issued back to back
-    # on one stream. Untimed by the driver.
-    one_at_a_time = None
-    if world == 1:
-        scene.set_frames_in_flight(1)
-        n_one = max(4, min(args.steps, 20))
-        for _ in range(2):
-            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(n_one):
-            scene.render_device(p, rebuild_grid=not args.no_rebuild, d_u8=part_bufs[0].data_ptr(), stream=lane_handles[0])
-        torch.cuda.synchronize()
-        dt_one = (time.perf_counter() - t1) / n_one
-        st_o = [scene.stats_at(i) for i in range(n_one)]
-        one_at_a_time = {"ms_per_frame": round(dt_one * 1e3, 4), "mrays": round(rays_local / dt_one / 1e6, 2), "frames": n_one,
-                         "build": round(float(np.mean([x["ms_build"] for x in st_o])), 4), "render": round(float(np.mean([x["ms_render"] for x in st_o])), 4)}
-        scene.set_frames_in_flight(depth)
-
+    if ms_render_alone is None:
+        ms_render_alone, ms_build_alone = ms_render, ms_build
+    if one_at_a_time is not None:
+        one_at_a_time["mrays"] = round(rays_local / (one_at_a_time["ms_per_frame"] * 1e-3) / 1e6, 2)
     # N > 1: the gathered, de-interleaved frame must be the frame one GPU renders alone (untimed check on rank 0)
     frame_check = None
     if multi and rank == 0:
@@ -440,7 +449,7 @@ def main():
                                      "note": "start to end of one k_trace launch in the timed region (the duration a profiler shows); with frames in flight it runs beside "
                                              "the kernels of %d other frames and is stretched by them" % (n_lanes - 1)},
                 "alone": {"ms": round(ms_render_alone, 4), "achieved": round((f32 + f64) / t_render_alone / 1e12, 4), "frac": round(t_peak / t_render_alone, 5),
-                          "note": "the same launch, same configuration, with the GPU to itself (frames one after the other on one stream, after the timed region)"},
+                          "note": "the same launch, same configuration, with the GPU to itself (frames one after the other on one stream, before the timed region)"},
                 "traffic": traffic,
                 "traffic_note": "HBM-side bytes of one k_trace launch from the L2 fabric counters (profiles/traffic.json: separate rocprofv3 --pmc passes, FETCH_SIZE doubled on gfx950)",
                 "note": "flops of the triangle tests k_trace executes (%d; the reference's early-exit order needs %d, the rest are skipped by the per-run "
