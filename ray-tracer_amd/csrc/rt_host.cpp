@@ -723,16 +723,27 @@ static int scene_ensure_refs(rt_scene* s, WorkSet& w) {
     return RT_OK;
 }
 
+// What the voxel lists of a frame hold: triangle indices (4 bytes per reference, the render kernel gathers the records) or
+// copies of the 48-byte test records. Indices make the build cheaper (0.21 -> 0.18 ms on the 3.6 M-triangle stand-in) and
+// the trace 2 % slower. A rank's share of a frame on several GPUs has the whole build and a fraction of the trace, so it
+// takes indices; for whole frames of large meshes the two balance out slightly in favour of indices (stand-in 0.916 ->
+// 0.902 ms one frame at a time, 0.584 -> 0.576 ms per frame with four in flight), for small meshes there is nothing in it.
+static bool want_indexed(const rt_scene* s, int part_count) {
+    if (s->indexed_override >= 0) return s->indexed_override != 0;
+    return part_count > 1 || s->n_tris() > 65536;
+}
+
 static int scene_build_grid_async(rt_scene* s, WorkSet& w, hipStream_t st) {
     int rc = scene_ensure_refs(s, w);
     if (rc) return rc;
     const bool first = !w.build_clean;
     w.build_clean = false;
-    if ((rc = build_grid_async(s, scene_mem(s, w), first, st, nullptr, nullptr))) return rc;
+    const bool indexed = want_indexed(s, 1);          // what a whole frame rendered from this grid will ask for
+    if ((rc = build_grid_async(s, scene_mem(s, w, indexed), first, st, nullptr, nullptr))) return rc;
     w.grid_valid = true;
     w.build_clean = true;
     w.grid_sorted = s->want_sorted();
-    w.grid_indexed = false;
+    w.grid_indexed = indexed;
     return RT_OK;
 }
 
@@ -992,10 +1003,7 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     hipStream_t st = (hipStream_t)stream;
     WorkSet* w = nullptr;
     if ((rc = scene_enter_stream(s, st, &w))) return rc;
-    // A rank's share of a frame on several GPUs: the grid build is the same for every share while the trace shrinks with it,
-    // so there the voxel lists hold triangle indices (build 0.23 -> 0.18 ms on the 3.6 M-triangle stand-in, trace 2...5 %
-    // slower: a gain from two GPUs on, a loss for whole frames).
-    const bool indexed = s->indexed_override >= 0 ? s->indexed_override != 0 : p->part_count > 1;
+    const bool indexed = want_indexed(s, p->part_count);
     const bool rebuild = rebuild_grid || !w->grid_valid || w->grid_sorted != s->want_sorted() || w->grid_indexed != indexed;
     // working memory of the frame, grown when the triangle list or the frame size has grown
     const size_t tiles = frame_tiles(p);

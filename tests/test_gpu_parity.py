@@ -286,6 +286,36 @@ def test_indexed_voxel_lists_give_the_same_frames(rt, O, plane10, monkeypatch, s
     s.close()
 
 
+@pytest.mark.parametrize("indexed", ["0", "1"])
+def test_both_list_layouts_on_a_large_crowded_mesh(rt, O, monkeypatch, indexed):
+    """Meshes of more than 65,536 triangles get voxel lists of triangle indices by default, smaller ones copies of the test
+    records. Both layouts, forced (RT_INDEXED_RECS), through the render kernel for crowded grids (RT_OWN_PATH=0), which is
+    built once per layout: a crowded mesh with duplicated triangles against the oracle, full walk and early exit."""
+    import torch
+    monkeypatch.setenv("RT_INDEXED_RECS", indexed)
+    monkeypatch.setenv("RT_OWN_PATH", "0")
+    tmp = rt.Scene(); tmp.load_mesh(BLUB); v9 = rt.subdivide(tmp.triangles(), 2).copy(); tmp.close()
+    v9[:, 0::3] += 1.5
+    v9 = np.concatenate([v9, v9[::7], v9[::5]])
+    assert len(v9) > 65536
+    o = O.OracleScene(); o.add_obj(SPOT); o.add_triangles(v9, (30, 200, 90))
+    W, H = 400, 260
+    o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0))
+    s = rt.Scene(); s.load_mesh(SPOT); s.add_triangles(v9, (30, 200, 90))
+    rgb_d = torch.empty((H, W, 3), dtype=torch.float32, device="cuda"); ids_d = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    for mode in (rt.RT_WALK_FULL, rt.RT_WALK_EARLY):
+        p = rt.default_params(W, H, walk_mode=mode)
+        for _ in range(2):
+            s.render_device(p, rebuild_grid=True, d_rgb=rgb_d.data_ptr(), d_ids=ids_d.data_ptr())
+            torch.cuda.synchronize()
+            if mode == rt.RT_WALK_FULL:
+                check_image(rgb_d.cpu().numpy(), ids_d.cpu().numpy(), o_rgb, o_ids)
+            else:       # early exit: documented rounding-level ties may move single pixels; the bar still holds
+                n_id, _ = check_image(rgb_d.cpu().numpy(), ids_d.cpu().numpy(), o_rgb, o_ids, exact=False)
+                assert n_id <= 4
+    s.close()
+
+
 def test_scene_grows_between_frames(rt, plane10):
     """The build kernels leave their counters reset for the next build of the scene; a triangle list that grows after
     frames have been rendered starts from scratch and gives the frames of a scene that was loaded in one go."""
