@@ -44,6 +44,13 @@ int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out);
  * No counterpart in the reference. */
 int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n);
 
+/* What the render kernel of an earlier frame of the scene reported about its triangle tests: record runs streamed and
+ * (run, ray) trips that found a candidate triangle, and whether the next frame would take the kernel variant that finishes
+ * a run's hit trips together (it does from 12 such trips per run on; RT_DEFER=0/1 in the environment forces it). The
+ * report of a frame reaches the host when the next frame on the same working set starts its grid build; nothing waits
+ * for it. No counterpart in the reference (Serial/raytracer.cpp has one code path). */
+int rt_scene_test_feedback(rt_scene* s, uint64_t* runs, uint64_t* hit_trips, int* deferred_variant);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,7 +82,7 @@ EXPORTS = [
     "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_add_obj_material", "rt_scene_add_triangles_material", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
-    "rt_render_device", "rt_render_device_noalloc", "rt_scene_set_frames_in_flight", "rt_scene_frames_in_flight", "rt_streams_create", "rt_streams_destroy", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_unit_costs",
+    "rt_render_device", "rt_render_device_noalloc", "rt_scene_set_frames_in_flight", "rt_scene_frames_in_flight", "rt_streams_create", "rt_streams_destroy", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_unit_costs", "rt_scene_test_feedback",
     "rt_deinterleave_device", "rt_selftest_division", "rt_comm_create", "rt_comm_destroy", "rt_comm_size", "rt_gather_bands",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
@@ -137,6 +137,7 @@ def lib():
     L.rt_scene_last_counts.argtypes = [vp, vp]
     L.rt_scene_record_order.argtypes = [vp, vp, vp]
     L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
+    L.rt_scene_test_feedback.argtypes = [vp, vp, vp, vp]
     L.rt_render_device_noalloc.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rt_scene_set_frames_in_flight.argtypes = [vp, i32]
     L.rt_scene_frames_in_flight.argtypes = [vp]
@@ -302,6 +303,13 @@ class Scene:
         out = np.zeros(n, np.uint32)
         k = _check(lib().rt_scene_unit_costs(self.h, out.ctypes.data, n))
         return out[:k]
+
+    def test_feedback(self):
+        """(record runs streamed, trips with a candidate triangle, deferred kernel variant next?) as reported by an earlier
+        frame; see rt_scene_test_feedback."""
+        r, h, d = C.c_uint64(), C.c_uint64(), C.c_int()
+        _check(lib().rt_scene_test_feedback(self.h, C.byref(r), C.byref(h), C.byref(d)))
+        return r.value, h.value, bool(d.value)
 
     def set_counting(self, enable):
         _check(lib().rt_scene_set_counting(self.h, int(bool(enable))))

@@ -11,6 +11,7 @@
 #define RT_WORK_LIST_COUNTS 32                     // first work[] word of the per-list tile counts (128 bytes after the head)
 #define RT_COST_SUM_PARTS 32u                       // partial sums of the cost estimate (power of two)
 #define RT_COUNTER_WORDS 88                        // 24 frame counters, 32 work-list words (64 x u32), 32 partial sums of the cost estimate
+#define RT_COUNTER_FEEDBACK 20                     // frame counter the render kernel adds its streamed runs (low half) and hit trips (high half) to
 #define RT_QUEUE_LISTS 16                          // tile lists the trace kernel serves in order (cost classes)
 
 // Grid description, resident in device memory: k_grid_setup writes the geometry, k_scan_apply writes n_refs.
@@ -54,6 +55,8 @@ struct RtFrame {
     int32_t cull_min;             // voxels with at least this many triangles get the per-run box test
     int32_t own_path;             // 1 = trace kernel with the lane = ray path for voxels of a few records (0 for grids known to be
                                   // crowded: the plain kernel needs fewer registers)
+    int32_t defer;                // 1 = trace kernel variant that finishes the hit trips of a run together, lane = ray (frames in
+                                  // which most trips find a triangle; only with own_path == 0)
 };
 
 // Device pointers of one scene.
@@ -122,6 +125,7 @@ struct RtBuildDev {
     float4* blk_bounds;           // 3 * (ref_cap / 64 + 2)
     uint32_t ref_cap;
     unsigned long long* counters; // RT_COUNTER_WORDS words the render kernels of the frame count in; the build clears them (may be NULL)
+    unsigned long long* feedback; // pinned host memory: the build copies counters[RT_COUNTER_FEEDBACK] of the frame before here (may be NULL)
     unsigned long long* stamp;    // when not NULL, the first kernel of the build writes the 100 MHz real-time clock here (frame start)
     int32_t indexed;              // 1: recs holds one uint32 triangle index per reference instead of the 48-byte record
     int32_t sorted;               // 1: voxel lists in ascending triangle index (scatter, row sort, ranking; needs ref_tri, ref_cell,
@@ -163,6 +167,7 @@ hipError_t rt_launch_upload_convert(const float* d_tri9, const uint32_t* d_mesh,
 // bounds + set-up, count, scan -> grid.n_refs known. `first`: the scene's build state has not been left behind clean by a
 // completed build (k_build_init runs)
 hipError_t rt_launch_build_phase1(RtBuildDev b, bool first, hipStream_t st);
+hipError_t rt_launch_counters_reset(unsigned long long* counters, unsigned long long* feedback, hipStream_t st);
 hipError_t rt_launch_run_area(RtBuildDev b, double* out, hipStream_t st);   // adds the summed surface area of the run boxes to *out
 hipError_t rt_launch_build_phase2(RtBuildDev b, hipStream_t st);   // scatter, per-cell order, record emit
 hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, RtRenderWork wk, hipStream_t st);   // classify, estimate, cost classes

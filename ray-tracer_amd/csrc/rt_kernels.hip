@@ -292,7 +292,16 @@ __global__ void k_scan_sums(RtBuildDev b) {
     __shared__ uint32_t wsum[4];
     // the frame's counters and work-list words start at zero: cleared here, by a kernel the frame launches anyway before
     // anything uses them, instead of by a memset of its own (one launch less in the frame's chain)
-    if (b.counters && blockIdx.x == 0 && threadIdx.x < RT_COUNTER_WORDS) b.counters[threadIdx.x] = 0ull;
+    // The word the previous frame's render kernel counted its streamed runs and hit trips in goes to the host first (a
+    // location in pinned host memory the host looks at, without waiting, when it picks the next frame's kernel variant).
+    if (b.counters && blockIdx.x == 0) {
+        if (threadIdx.x == 0 && b.feedback) {
+            const unsigned long long w = b.counters[RT_COUNTER_FEEDBACK];
+            if (w) __atomic_store_n(b.feedback, w, __ATOMIC_RELAXED);
+        }
+        __syncthreads();
+        if (threadIdx.x < RT_COUNTER_WORDS) b.counters[threadIdx.x] = 0ull;
+    }
     const int n_cells = b.grid->n_cells;
     uint32_t base = blockIdx.x * RT_SCAN_CHUNK;
     uint32_t s = 0;
@@ -802,6 +811,22 @@ __global__ void __launch_bounds__(256) k_run_area(RtBuildDev b, double* out) {
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
+// Frames without a grid build: the frame counters start at zero, after the word the previous frame's render kernel reported
+// in has gone to the host (frames with a build do both in k_scan_sums).
+__global__ void k_counters_reset(unsigned long long* counters, unsigned long long* feedback) {
+    if (threadIdx.x == 0 && feedback) {
+        const unsigned long long w = counters[RT_COUNTER_FEEDBACK];
+        if (w) __atomic_store_n(feedback, w, __ATOMIC_RELAXED);
+    }
+    __syncthreads();
+    if (threadIdx.x < RT_COUNTER_WORDS) counters[threadIdx.x] = 0ull;
+}
+
+hipError_t rt_launch_counters_reset(unsigned long long* counters, unsigned long long* feedback, hipStream_t st) {
+    k_counters_reset<<<1, 128, 0, st>>>(counters, feedback);
+    return hipGetLastError();
+}
+
 hipError_t rt_launch_run_area(RtBuildDev b, double* out, hipStream_t st) {
     k_run_area<<<256, 256, 0, st>>>(b, out);
     return hipGetLastError();
@@ -902,6 +927,7 @@ struct WalkCount {           // work counters of one ray (only maintained by the
     uint32_t rounds, slots, lanes;   // per wavefront (identical in every lane): scheduling rounds, voxel visits, triangle tests executed
     uint32_t cyc_step, cyc_test;     // shader cycles spent in the two phases
     uint32_t items, trips, cyc_cull; // record runs streamed, (run, ray) test iterations, cycles of the run culling
+    uint32_t fb_items, fb_hits;      // kept by every build of the kernel: record runs streamed, (run, ray) trips with a candidate triangle
 };
 
 // Primary ray of pixel (x, y), Serial/raytracer.cpp:153-161; xw and yw are evaluated in double.
@@ -1439,6 +1465,10 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
     return t;
 }
 
+// kernel variant DEFER: runs tested by at least this many rays resolve single-candidate trips together after the ray loop
+#ifndef RT_DEFER_MIN_RAYS
+#define RT_DEFER_MIN_RAYS 16
+#endif
 // empty voxels a ray may cross in one round of wave_walk before the round goes on without it
 #ifndef RT_STEPS_PER_ROUND
 #define RT_STEPS_PER_ROUND 8
@@ -1496,7 +1526,8 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 // for the early-exit comparison (never stops a ray the exact comparison would not stop), st.id is the nearest triangle.
 // IDX says what the voxel lists hold, where the kernel is built for one answer: 0 records, 1 triangle indices, 2 either
 // (RtSceneDev::indexed decides at run time).
-template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT, bool OWN, int RULE = 0, int IDX = 2>
+// DEFER: the kernel variant for frames in which most trips find a triangle (see process()).
+template <bool ANY_HIT, bool SHARED_ORIGIN, bool COUNT, bool OWN, int RULE = 0, int IDX = 2, bool DEFER = false>
 __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* bitmap, int lane, bool active, float ox,
                                           float oy, float oz, float dx, float dy, float dz, float mint, bool use_eps, float eps,
                                           bool early, float slack, uint32_t cull_min, int ray_lanes, Nearest& st, WalkCount& wc,
@@ -1789,6 +1820,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             const unsigned long long have_m = __ballot(have);
             unsigned long long lm = cur.rays & __ballot(alive);          // rays that were hit meanwhile (shadow query) drop out
             if (COUNT) { wc.lanes += (uint32_t)__popcll(have_m) * (uint32_t)__popcll(lm); wc.items += 1; wc.trips += (uint32_t)__popcll(lm); }
+            wc.fb_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc.fb_items + 1u));      // a scalar register, not one per lane
             if (lm) {
                 // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
                 double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
@@ -1797,6 +1829,13 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     p_e2s = minor_f32(t.e2y, sz, sy, t.e2z);
                     p_e1s = minor_f32(t.e1y, sz, sy, t.e1z);
                 }
+                // DEFER: a ray with ONE candidate triangle in this run does not go through the divisions in its trip (a few
+                // dozen instructions for one busy lane): the ray's lane notes the triangle's lane, and after the loop all
+                // such rays finish their tests together, lane = ray (below). One or two such rays take the loop once more
+                // instead, and runs with few rays do not defer at all.
+                int dc = -1;
+                bool at_once = !DEFER || __popcll(lm) < RT_DEFER_MIN_RAYS;
+                for (;;) {
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
                     lm &= lm - 1;
@@ -1825,7 +1864,10 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                                                     __builtin_amdgcn_fcmp(fabs(bnum + gnum), fabs(A) * (1.0 + 1e-12), 13);
                     unsigned long long pm = 0;
                     double tt = 0.0;
-                    if (cand) {
+                    if (cand) wc.fb_hits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc.fb_hits + 1u));
+                    if (DEFER && !at_once && (cand & (cand - 1ull)) == 0ull) {
+                        if (cand && lane == i) dc = __ffsll((long long)cand) - 1;
+                    } else if (cand) {
                         // The three quotients have one denominator: where the exponents of all operands allow it (see
                         // div_rcp) the reciprocal part of the division is evaluated once. Any candidate lane outside the
                         // window (zeros, infinities and NaNs included) sends the wavefront down the plain path.
@@ -1875,6 +1917,60 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                             }
                         }
                     }
+                }
+                if (!DEFER) break;
+                // the rays that noted a candidate
+                const unsigned long long dm = __ballot(dc >= 0);
+                if (dm == 0ull) break;
+                if (__popcll(dm) < 3) {                    // one or two rays: their trips again, with the divisions
+                    lm = dm; dc = -1; at_once = true;
+                    wc.fb_hits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc.fb_hits - (uint32_t)__popcll(dm)));   // counted once
+                    continue;
+                }
+                // lane = ray: the ray fetches its candidate's record from that lane and repeats the trip's expressions
+                // on the same values (same results), then the exact test, every ray at once
+                {
+                    const int src = dc >= 0 ? dc : lane;
+                    const float c_v0x = __shfl(t.v0x, src), c_v0y = __shfl(t.v0y, src), c_v0z = __shfl(t.v0z, src);
+                    const float c_e1x = __shfl(t.e1x, src), c_e1y = __shfl(t.e1y, src), c_e1z = __shfl(t.e1z, src);
+                    const float c_e2x = __shfl(t.e2x, src), c_e2y = __shfl(t.e2y, src), c_e2z = __shfl(t.e2z, src);
+                    const double c_m12 = __shfl(t.m12, src);
+                    const int c_id = __shfl((int)t.id, src);
+                    const double c_sx = c_v0x - ox, c_sy = c_v0y - oy, c_sz = c_v0z - oz;       // float subtractions, then widened
+                    const double q_e2s = minor_f32(c_e2y, c_sz, c_sy, c_e2z);
+                    const double q_e1s = minor_f32(c_e1y, c_sz, c_sy, c_e1z);
+                    const double q_e2d = minor_f32(c_e2y, ddz, ddy, c_e2z);
+                    const double q_e1d = minor_f32(c_e1y, ddz, ddy, c_e1z);
+                    const double q_sd = minor_f32(c_sy, ddz, ddy, c_sz);
+                    const double A = c_e1x * q_e2d - c_e2x * q_e1d + ddx * c_m12;
+                    const double bnum = c_sx * q_e2d - c_e2x * q_sd - ddx * q_e2s;
+                    const double gnum = c_e1x * q_sd - c_sx * q_e1d + ddx * q_e1s;
+                    const double tnum = c_e1x * q_e2s - c_e2x * q_e1s + c_sx * c_m12;
+                    const uint32_t ea = exponent_field(A), eb = exponent_field(bnum), eg = exponent_field(gnum),
+                                   et = (!ANY_HIT || RULE == 1) ? exponent_field(tnum) : ea;
+                    const uint32_t e_lo = min(min(ea, eb), min(eg, et)), e_hi = max(max(ea, eb), max(eg, et));
+                    double beta, gamma, tq;
+                    if ((dm & ~(__builtin_amdgcn_uicmp(e_lo, RT_DIV_EXP_LO, 35) & __builtin_amdgcn_uicmp(e_hi, RT_DIV_EXP_HI, 37))) == 0ull) {
+                        const double rcp_a = div_rcp(A);
+                        beta = div_with_rcp(bnum, A, rcp_a); gamma = div_with_rcp(gnum, A, rcp_a); tq = div_with_rcp(tnum, A, rcp_a);
+                    } else {
+                        beta = bnum / A; gamma = gnum / A; tq = tnum / A;
+                    }
+                    bool pass = dc >= 0 && beta > 0.0 && gamma > 0.0 && beta + gamma < 1.0;
+                    if (RULE == 1 && ANY_HIT) pass = pass && tq > (double)eps && tq < (double)INFINITY;
+                    if (pass) {
+                        if (ANY_HIT) {
+                            hit = true; alive = false;
+                            if (COUNT) wc.tests -= e - (base + (uint32_t)dc + 1u);      // tests the reference order skips
+                        } else if (RULE == 0) {
+                            hit = true;
+                            if (!use_eps || tq > (double)eps) vb_add(vb, tq, c_id);
+                        } else if (tq > (double)eps && (tq < pb_t || (tq == pb_t && c_id < pb_id))) {
+                            pb_t = tq; pb_id = c_id;
+                        }
+                    }
+                }
+                break;
                 }
             }
         };
@@ -2101,7 +2197,7 @@ __device__ __forceinline__ void trace_unit_parallel(const RtSceneDev& s, const R
     out_r = Rr; out_g = Rg; out_b = Rb;
 }
 
-template <bool COUNT, bool OWN, int MODE = 0, int IDX = 2>
+template <bool COUNT, bool OWN, int MODE = 0, int IDX = 2, bool DEFER = false>
 // Four blocks per CU (128 VGPRs, a few of them spilled) for the streamed path of crowded grids; three (144 VGPRs, nothing
 // spilled) for the variants that also hold the small-voxel loop, whose frames are bound by the longest chain of one wavefront
 // rather than by the number of wavefronts (measured: 1080p frame of a 5.8 k triangle mesh 0.176 -> 0.166 ms; the streamed
@@ -2134,6 +2230,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
     // units start early and are spread over many wavefronts while the bulk of the frame runs as large, efficient units.
     // frame counters are summed per wavefront and added to memory once, after the last unit
     uint32_t acc_hits = 0, acc_shadowed = 0;
+    unsigned long long acc_fb = 0;        // record runs streamed (low half) and trips with a candidate triangle (high half)
     unsigned long long acc_ray[6] = {0, 0, 0, 0, 0, 0}, acc_w[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_cyc = 0, max_rounds = 0;
     const long long wave_t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
     uint32_t slot_next = 0;
@@ -2190,7 +2287,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
         WalkCount wp = {}, ws = {};
         const long long t_start = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const unsigned long long rt_start = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        const bool hit_any = wave_walk<false, true, COUNT, OWN, 0, IDX>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
+        const bool hit_any = wave_walk<false, true, COUNT, OWN, 0, IDX, DEFER>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
                                                        sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, per_unit, st, wp);
         float colr = 0.f, colg = 0.f, colb = 0.f;
         float poix = 0.f, poiy = 0.f, poiz = 0.f, sx = 0.f, sy = 0.f, sz = 1.f;
@@ -2230,7 +2327,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
             sx = -(sh.light[0] - poix); sy = -(sh.light[1] - poiy); sz = -(sh.light[2] - poiz);
             normalize3(sx, sy, sz);
         }
-        const bool shadowed = wave_walk<true, false, COUNT, OWN, 0, IDX>(s, bitmap, lane, hit, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
+        const bool shadowed = wave_walk<true, false, COUNT, OWN, 0, IDX, DEFER>(s, bitmap, lane, hit, poix, poiy, poiz, sx, sy, sz, sh.eps, true, sh.eps,
                                                             true, 0.f, (uint32_t)f.cull_min, per_unit, st, ws);
         if (hit) {
             if (shadowed) { cr = cr * sh.shadow_scale; cg = cg * sh.shadow_scale; cb = cb * sh.shadow_scale; }
@@ -2240,6 +2337,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
             const unsigned long long hm = __ballot(hit), sm = __ballot(shadowed);
             acc_hits += (uint32_t)__popcll(hm);
             acc_shadowed += (uint32_t)__popcll(sm);
+            acc_fb += (unsigned long long)(wp.fb_items + ws.fb_items) | ((unsigned long long)(wp.fb_hits + ws.fb_hits) << 32);
             if (COUNT) {
                 const unsigned long long cyc = (unsigned long long)((long long)__builtin_amdgcn_s_memtime() - t_start);
                 acc_ray[0] += wp.entered; acc_ray[1] += wp.steps; acc_ray[2] += wp.tests;
@@ -2282,6 +2380,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
         if (lane == 0) {
             if (acc_hits) atomicAdd(&counters[0], (unsigned long long)acc_hits);
             if (acc_shadowed) atomicAdd(&counters[1], (unsigned long long)acc_shadowed);
+            if (acc_fb) atomicAdd(&counters[RT_COUNTER_FEEDBACK], acc_fb);
         }
         if (COUNT) {
 #pragma unroll
@@ -2354,6 +2453,8 @@ hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, Rt
         else k_trace<true, false><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     } else {
         if (f.own_path) k_trace<false, true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+        else if (f.defer && s.indexed) k_trace<false, false, 0, 1, true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
+        else if (f.defer) k_trace<false, false, 0, 0, true><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
         else if (s.indexed) k_trace<false, false, 0, 1><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
         else k_trace<false, false, 0, 0><<<blocks, RT_WAVES_PER_BLOCK * 64, lds, st>>>(ta);
     }

@@ -316,6 +316,65 @@ def test_both_list_layouts_on_a_large_crowded_mesh(rt, O, monkeypatch, indexed):
     s.close()
 
 
+@pytest.mark.parametrize("defer", ["0", "1"])
+def test_deferred_hit_trips_give_the_same_frames(rt, O, plane10, monkeypatch, defer):
+    """The render kernel variant that finishes a run's hit trips together, lane = ray (taken by frames in which most trips find
+    a triangle; RT_DEFER forces it on or off), through the kernel for crowded grids: the flat golden scene, where every ray
+    hits in its one trip, and a crowded mesh against the oracle."""
+    import torch
+    monkeypatch.setenv("RT_DEFER", defer)
+    monkeypatch.setenv("RT_OWN_PATH", "0")
+    s, W, H, cam = _scene(rt, "plane10_480x270", plane10)
+    g_ids, g_rgb = golden("plane10_480x270")
+    for mode in (rt.RT_WALK_FULL, rt.RT_WALK_EARLY):
+        rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=mode, **cam_kwargs(cam)))
+        check_image(rgb, ids, g_rgb, g_ids)
+    assert s.test_feedback()[2] == (defer == "1")
+    s.close()
+    tmp = rt.Scene(); tmp.load_mesh(BLUB); v9 = rt.subdivide(tmp.triangles(), 2).copy(); tmp.close()
+    v9[:, 0::3] += 1.5
+    o = O.OracleScene(); o.add_obj(SPOT); o.add_triangles(v9, (30, 200, 90))
+    W, H = 400, 260
+    cam = dict(cam_pos=(1.2, 0.3, -1.6), cam_target=(1.4, 0.0, 0.0))          # close: tiles full of rays on one patch
+    o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0, **cam))
+    s = rt.Scene(); s.load_mesh(SPOT); s.add_triangles(v9, (30, 200, 90))
+    rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL, **cam))
+    check_image(rgb, ids, o_rgb, o_ids)
+    s.close()
+
+
+def test_kernel_variant_follows_the_frames(rt, plane10, monkeypatch):
+    """Without RT_DEFER the variant is chosen from what earlier frames of the scene reported: a flat mesh that fills a large
+    frame moves to the variant after its first frames and its frames stay, bit for bit, those of a scene that never takes
+    it; a mesh seen from afar does not move."""
+    monkeypatch.setenv("RT_OWN_PATH", "0")
+    _, _, _, cam = _scene(rt, "plane10_480x270", plane10)
+    W, H = 1920, 1080
+    p = rt.default_params(W, H, **cam_kwargs(cam))
+    monkeypatch.setenv("RT_DEFER", "0")
+    s0, _, _, _ = _scene(rt, "plane10_480x270", plane10)
+    rgb0, _, ids0 = s0.render(p)
+    s0.close()
+    monkeypatch.delenv("RT_DEFER", raising=False)
+    s, _, _, _ = _scene(rt, "plane10_480x270", plane10)
+    seen = []
+    for _ in range(4):
+        rgb, _, ids = s.render(p)
+        assert np.array_equal(ids, ids0) and np.array_equal(bits(rgb), bits(rgb0))
+        seen.append(s.test_feedback())
+    runs, hits, deferred = seen[-1]
+    assert runs >= 1024 and hits >= 12 * runs and deferred, seen
+    assert seen[-1][:2] == seen[-2][:2], seen              # the variant counts what the plain kernel counts
+    s.close()
+    s, W, H, cam = _scene(rt, "main_512x512", plane10)
+    g_ids, g_rgb = golden("main_512x512")
+    for _ in range(3):
+        rgb, _, ids = s.render(rt.default_params(W, H, **cam_kwargs(cam)))
+        check_image(rgb, ids, g_rgb, g_ids)
+    assert not s.test_feedback()[2]
+    s.close()
+
+
 def test_scene_grows_between_frames(rt, plane10):
     """The build kernels leave their counters reset for the next build of the scene; a triangle list that grows after
     frames have been rendered starts from scratch and gives the frames of a scene that was loaded in one go."""
