@@ -1,5 +1,6 @@
+"""Build, trace and total time of every frame of one burst of 20 stand-in frames, four in flight (python tools/burstlat.py) (GPU)"""
 import importlib, sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 rt = importlib.import_module("ray-tracer_amd")
 scene, pkw, W, H, label = bench.build_workload(rt, "nefertiti4k")
