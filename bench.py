@@ -130,8 +130,31 @@ def cpu_baseline(rt, scene, pkw, W, H, walk, budget_s=12.0):
     parity = {"against": "oracle, full walk (what the reference executes)", "gpu_walk": "full" if walk == rt.RT_WALK_FULL else "early",
               "pixels_checked": n_px, "rows_checked": rows_done, "id_mismatch": n_id, "colour_gt_1_255": n_col, "colour_bits_differ": n_bits,
               "agreement": round(1.0 - n_col / max(n_px, 1), 7)}
+    # The reference ITSELF (Serial/raytracer.cpp compiled from its own sources into oracle/_ref/libref.so, where that file
+    # was built) beside the port on the reference's own CPU-runnable case, configs[0]: spot at 640x480, same core. This
+    # says what the port's number is worth as a stand-in for the reference on the large frame above.
+    ref_check = None
+    if O.ref_available():
+        spot = os.path.join(MESH, "spot_triangulated.obj")
+        r = O.RefScene()
+        r.add_obj(spot)
+        r_grid = r.build_grid()
+        r_rgb, _, r_ms = r.render(640, 480, want_ids=False)
+        o2 = O.OracleScene()
+        o2.add_obj(spot)
+        o_grid = o2.build_grid()
+        c2 = O.Counters()
+        o_rgb2, _, o_ms = o2.render(O.default_params(640, 480, walk_mode=0), want_ids=False, counters=c2)
+        n_rays = 640 * 480 + c2.hits
+        ref_check = {"workload": "configs[0]: spot_triangulated.obj 640x480, Serial camera, %d rays" % n_rays, "cores": 1,
+                     "reference": {"kind": "reference", "value": round(n_rays / (r_grid + r_ms) / 1e3, 4), "unit": "Mrays/s",
+                                   "frame_ms": round(r_grid + r_ms, 1), "grid_ms": round(r_grid, 1)},
+                     "port": {"kind": "port", "value": round(n_rays / (o_grid + o_ms) / 1e3, 4), "unit": "Mrays/s",
+                              "frame_ms": round(o_grid + o_ms, 1), "grid_ms": round(o_grid, 1)},
+                     "images_bit_equal": bool(np.array_equal(r_rgb.view(np.uint32), o_rgb2.view(np.uint32)))}
     return parity, {
         "value": round(est_rays / est_frame_ms / 1e3, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+        "reference_check": ref_check,
         "sample": "%d of %d rows (every %dth row, %d passes) of the same frame, full-walk like the reference; "
                   "frame time extrapolated = grid build %.1f ms + rows %.1f ms / %.4f" % (rows_done, H, stride, rows_done * stride // H + 1, grid_ms, t_ms, frac),
         "est_frame_ms": round(est_frame_ms, 1),
