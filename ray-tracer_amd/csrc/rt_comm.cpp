@@ -69,7 +69,10 @@ extern "C" int rt_comm_create(int32_t n_devices, const int32_t* devices, rt_comm
     *out = nullptr;
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return rt_set_error(RT_ERR_NO_DEVICE, "no HIP device");
-    if (!rccl().ok) return rt_set_error(RT_ERR_HIP, "RCCL (librccl.so.1) cannot be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    if (!rccl().ok) {
+        const char* why = dlerror();          // a second call would return NULL: the message is handed out once
+        return rt_set_error(RT_ERR_HIP, "RCCL (librccl.so.1) cannot be loaded: %s", why ? why : "symbols missing");
+    }
     rt_comm* c = new (std::nothrow) rt_comm();
     if (!c) return rt_set_error(RT_ERR_NOMEM, "out of host memory");
     try {
