@@ -473,6 +473,11 @@ def main():
                                              "the kernels of %d other frames and is stretched by them" % (n_lanes - 1)},
                 "alone": {"ms": round(ms_render_alone, 4), "achieved": round((f32 + f64) / t_render_alone / 1e12, 4), "frac": round(t_peak / t_render_alone, 5),
                           "note": "the same launch, same configuration, with the GPU to itself (frames one after the other on one stream, before the timed region)"},
+                "one_at_a_time": ({"ms": one_at_a_time["render"], "achieved": round((f32 + f64) / (one_at_a_time["render"] * 1e-3) / 1e12, 4),
+                                   "frac": round(t_peak / (one_at_a_time["render"] * 1e-3), 5),
+                                   "note": "the launch as the library issues it for one frame at a time (every wavefront slot of the GPU, nothing beside it): "
+                                           "the duration a kernel trace of `bench.py --in-flight 1` shows (profiles/*_one_at_a_time_kernel_stats.csv)"}
+                                  if one_at_a_time and one_at_a_time["render"] > 0 else None),
                 "traffic": traffic,
                 "traffic_note": "HBM-side bytes of one k_trace launch from the L2 fabric counters (profiles/traffic.json: separate rocprofv3 --pmc passes, FETCH_SIZE doubled on gfx950)",
                 "note": "flops of the triangle tests k_trace executes (%d; the reference's early-exit order needs %d, the rest are skipped by the per-run "
