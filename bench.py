@@ -152,9 +152,52 @@ def cpu_baseline(rt, scene, pkw, W, H, walk, budget_s=12.0):
                      "port": {"kind": "port", "value": round(n_rays / (o_grid + o_ms) / 1e3, 4), "unit": "Mrays/s",
                               "frame_ms": round(o_grid + o_ms, 1), "grid_ms": round(o_grid, 1)},
                      "images_bit_equal": bool(np.array_equal(r_rgb.view(np.uint32), o_rgb2.view(np.uint32)))}
+    port = {"value": round(est_rays / est_frame_ms / 1e3, 4), "unit": "Mrays/s", "cores": 1, "kind": "port", "est_frame_ms": round(est_frame_ms, 1)}
+    # The reference ITSELF on the benchmarked frame: the scene's triangles go through an OBJ file its own loader reads back
+    # bit for bit, its own GridAccel is built, and evenly spread rows of the frame are rendered by its fast_trace (about 4 s
+    # worth); the rows are compared with the oracle's. This is the headline CPU number where libref.so exists.
+    if O.ref_available() and all(k in ("cam_pos", "cam_target") for k in pkw):
+        try:
+            tri = scene.triangles()
+            path = "/tmp/rt_bench_scene_%d.obj" % os.getpid()
+            t_w = time.time()
+            O.write_obj(path, tri)
+            t_w = time.time() - t_w
+            r = O.RefScene()
+            t_l = time.time()
+            n_loaded = r.add_obj(path, False)
+            t_l = time.time() - t_l
+            os.remove(path)
+            tris_equal = n_loaded == tri.shape[0] and bool(np.array_equal(r.triangles().view(np.uint32), tri.view(np.uint32)))
+            r_grid = r.build_grid()
+            cam = tuple(pkw.get("cam_pos", (3, 5, 3))) + tuple(pkw.get("cam_target", (0, 0, 0))) + (0, -1, 0, 45)
+            per_row = t_ms / max(rows_done, 1)
+            stride_r = max(1, int(np.ceil(1.4 * per_row * H / 4000.0)))
+            r_ms, r_rows, r_rays, rows_equal = 0.0, 0, 0, True
+            for y in range(stride_r // 2, H, stride_r):
+                c1 = O.Counters()
+                o_rgb, _, _ = o.render(p, y0=y, y1=y + 1, want_rgb=True, want_ids=False, counters=c1)
+                r_rgb, _, ms = r.render(W, H, y0=y, y1=y + 1, cam=cam, want_ids=False)
+                r_ms += ms; r_rows += 1; r_rays += W + c1.hits
+                rows_equal = rows_equal and bool(np.array_equal(r_rgb.view(np.uint32), o_rgb.view(np.uint32)))
+            r_frac = r_rows / H
+            r_frame_ms = r_grid + r_ms / r_frac
+            return parity, {
+                "value": round((r_rays / r_frac) / r_frame_ms / 1e3, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                "sample": "Serial/raytracer.cpp itself (oracle/_ref/libref.so, compiled from the reference's sources): its load_mesh on the scene written as OBJ "
+                          "(%.1f s to write, %.1f s to load, triangles bit-equal: %s), its GridAccel (%.1f ms), its fast_trace on %d of %d rows (every %dth row) of the "
+                          "same frame; frame time extrapolated = grid build + rows %.1f ms / %.4f" % (t_w, t_l, tris_equal, r_grid, r_rows, H, stride_r, r_ms, r_frac),
+                "est_frame_ms": round(r_frame_ms, 1),
+                "rows_bit_equal_to_oracle": rows_equal,
+                "port": dict(port, sample="the oracle (C restatement) on %d of %d rows of the same frame, full-walk like the reference; frame time extrapolated = "
+                                          "grid build %.1f ms + rows %.1f ms / %.4f" % (rows_done, H, grid_ms, t_ms, frac)),
+                "reference_check": ref_check,
+            }
+        except Exception as e:          # the reference leg is an extra: without it the port's number stands
+            port["reference_error"] = repr(e)
     return parity, {
-        "value": round(est_rays / est_frame_ms / 1e3, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-        "reference_check": ref_check,
+        "value": port["value"], "unit": "Mrays/s", "cores": 1, "kind": "port",
+        "reference_check": ref_check, "reference_error": port.get("reference_error"),
         "sample": "%d of %d rows (every %dth row, %d passes) of the same frame, full-walk like the reference; "
                   "frame time extrapolated = grid build %.1f ms + rows %.1f ms / %.4f" % (rows_done, H, stride, rows_done * stride // H + 1, grid_ms, t_ms, frac),
         "est_frame_ms": round(est_frame_ms, 1),

@@ -74,6 +74,7 @@ def lib():
         L.rto_render_rows.restype = C.c_double
         L.rto_render_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rto_quantize.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.rto_write_obj.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.rto_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.rto_params_default.argtypes = [C.c_void_p]
         _lib = L
@@ -186,6 +187,21 @@ def quantize(rgb):
     out = np.empty(rgb.shape, np.uint8)
     lib().rto_quantize(rgb.ctypes.data, rgb.size, out.ctypes.data)
     return out
+
+
+def write_obj(path, v9):
+    """Writes a triangle soup (n x 9 floats) as an indexed OBJ without texture indices; load_mesh(path, format_has_vt=False)
+    of the reference, or add_obj(path, False) here, reads the same floats back. Returns (vertices, faces)."""
+    v9 = np.ascontiguousarray(v9, dtype=np.float32)
+    pts = v9.reshape(-1, 3)
+    key = np.where(pts == 0, np.float32(0), pts)          # -0.0 and +0.0 print alike: one vertex
+    key = np.ascontiguousarray(key).view(np.dtype((np.void, 12))).ravel()
+    u, inv = np.unique(key, return_inverse=True)
+    verts = np.ascontiguousarray(u.view(np.float32).reshape(-1, 3))
+    idx = np.ascontiguousarray(inv.reshape(-1, 3), dtype=np.int32)
+    if lib().rto_write_obj(os.fsencode(path), verts.ctypes.data, verts.shape[0], idx.ctypes.data, idx.shape[0]) != 0:
+        raise OSError("cannot write " + path)
+    return verts.shape[0], idx.shape[0]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -665,3 +665,18 @@ int rto_write_ppm(const char* path, const float* rgb, int w, int h) {
     fclose(f);
     return ok ? 0 : -1;
 }
+
+/* Indexed triangles as OBJ text ("v x y z" with 9 significant digits, which a float survives; "f a b c", 1-based, no
+   texture index): the input the reference's load_mesh (Serial/raytracer.cpp:220-287, format_has_vt = false) reads back into
+   the same floats. For timing the compiled reference on meshes that exist only in memory. */
+int rto_write_obj(const char* path, const float* verts, int64_t nv, const int32_t* idx, int64_t nf) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    static char iobuf[1 << 22];
+    setvbuf(f, iobuf, _IOFBF, sizeof(iobuf));
+    for (int64_t i = 0; i < nv; ++i) fprintf(f, "v %.9g %.9g %.9g\n", (double)verts[3 * i], (double)verts[3 * i + 1], (double)verts[3 * i + 2]);
+    for (int64_t i = 0; i < nf; ++i) fprintf(f, "f %d %d %d\n", idx[3 * i] + 1, idx[3 * i + 1] + 1, idx[3 * i + 2] + 1);
+    int ok = !ferror(f);
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : -1;
+}

@@ -80,6 +80,8 @@ double rto_render_rows_parallel(const rto_scene* s, const rto_params* p, int y0,
 
 /* The PPM quantisation of Serial/raytracer.cpp:181-183. */
 void rto_quantize(const float* c, int64_t n, unsigned char* out);
+/* indexed triangles as OBJ text the reference's loader reads back bit for bit (format_has_vt = false) */
+int rto_write_obj(const char* path, const float* verts, int64_t nv, const int32_t* idx, int64_t nf);
 /* Writes "P6\nW H\n255\n" + quantised body (Serial/raytracer.cpp:178-185). Returns 0 on success. */
 int rto_write_ppm(const char* path, const float* rgb, int w, int h);
 
