@@ -31,6 +31,12 @@ int rt_scene_set_counting(rt_scene* s, int32_t enable);
  * bounds of all runs of 64 records with the records as the scatter leaves them (area[0]) and in ascending triangle index
  * (area[1]; both 0 when nothing was measured: small meshes, RT_SORTED_BUILD set), and whether frames sort (1) or not (0). */
 int rt_scene_record_order(rt_scene* s, double area[2], int32_t* sorted);
+/* The same measurement for the order in which the grid build visits the triangles of a large mesh (more than 65,536): the
+ * summed run area of the unsorted build when the triangles are taken along a space-filling curve through their centroids
+ * (*area_spatial; 0 when not measured), and whether frames build that way (1) or in the order of the file (0). A file in
+ * arbitrary triangle order builds and renders several times slower in its own order; no result depends on the choice.
+ * RT_TRI_ORDER=0/1 in the environment of rt_scene_create() pins it. */
+int rt_scene_triangle_order(rt_scene* s, double* area_spatial, int32_t* spatial);
 /* Counters of the last frame (zeros unless it was a counting frame); synchronises the device. */
 int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out);
 /* Diagnostics of the last counting frame, as 32-bit words; with t = tiles of the frame (8x8 pixels each):

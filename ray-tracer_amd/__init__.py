@@ -82,7 +82,7 @@ EXPORTS = [
     "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_add_obj_material", "rt_scene_add_triangles_material", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
-    "rt_render_device", "rt_render_device_noalloc", "rt_scene_set_frames_in_flight", "rt_scene_frames_in_flight", "rt_streams_create", "rt_streams_destroy", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_unit_costs", "rt_scene_test_feedback",
+    "rt_render_device", "rt_render_device_noalloc", "rt_scene_set_frames_in_flight", "rt_scene_frames_in_flight", "rt_streams_create", "rt_streams_destroy", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_triangle_order", "rt_scene_unit_costs", "rt_scene_test_feedback",
     "rt_deinterleave_device", "rt_selftest_division", "rt_comm_create", "rt_comm_destroy", "rt_comm_size", "rt_gather_bands",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
@@ -136,6 +136,7 @@ def lib():
     L.rt_scene_set_counting.argtypes = [vp, i32]
     L.rt_scene_last_counts.argtypes = [vp, vp]
     L.rt_scene_record_order.argtypes = [vp, vp, vp]
+    L.rt_scene_triangle_order.argtypes = [vp, vp, vp]
     L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
     L.rt_scene_test_feedback.argtypes = [vp, vp, vp, vp]
     L.rt_render_device_noalloc.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -298,6 +299,12 @@ class Scene:
         a, srt = (C.c_double * 2)(), C.c_int32()
         _check(lib().rt_scene_record_order(self.h, a, C.byref(srt)))
         return a[0], a[1], bool(srt.value)
+
+    def triangle_order(self):
+        """(area of the unsorted build in spatial order, frames build in spatial order?); see rt_scene_triangle_order."""
+        a, sp = C.c_double(), C.c_int32()
+        _check(lib().rt_scene_triangle_order(self.h, C.byref(a), C.byref(sp)))
+        return a.value, bool(sp.value)
 
     def unit_costs(self, n):
         out = np.zeros(n, np.uint32)

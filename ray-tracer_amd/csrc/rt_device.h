@@ -111,6 +111,8 @@ struct RtBuildDev {
     float2* tri_box;              // 3 float2 per triangle, made at upload: {lo.x, lo.y} {lo.z, hi.x} {hi.y, hi.z}
     float4* tri_rec;              // 3 float4 per triangle: the test record of the triangle (see emit_record), made at upload
     uint32_t n_tris;
+    const uint32_t* order;        // when not NULL (meshes above RT_WIDE_MAX_TRIS only): thread t of the count and scatter kernels takes
+                                  // triangle order[t], a permutation that puts spatial neighbours side by side (made at upload)
     float cube_root;              // 3.f * powf((float)T, 1.f/3.f), evaluated on the host (libm)
     RtGrid* grid;
     uint32_t* bounds_enc;         // 6 order-preserving encoded floats: lo xyz, hi xyz

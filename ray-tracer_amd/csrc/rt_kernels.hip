@@ -246,9 +246,10 @@ __device__ __forceinline__ void lane_groups(bool act, int c, int lane, int& head
 // form a group (lane_groups), and one lane adds the group's size. Neighbouring triangle indices tend to share voxels, also the ones
 // straddling a voxel border, so a wavefront issues a few atomics per round instead of one per reference.
 __global__ void __launch_bounds__(256) k_count(RtBuildDev b) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool valid = i < b.n_tris;
+    const bool valid = t < b.n_tris;
+    const uint32_t i = (valid && b.order) ? b.order[t] : t;
     int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
     const RtGrid g = *b.grid;                  // same address in every lane; in flight together with the vertex loads
     if (valid) tri_voxel_range(b, g, i, vmin, vmax);
@@ -371,15 +372,16 @@ __global__ void k_scan_apply(RtBuildDev b) {
 // group's slots with ONE atomic, all groups at once, so the wavefront waits for a single round trip per round. The
 // order inside a voxel is whatever the atomics produce; k_row_sort and k_order_emit restore ascending triangle index.
 __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const RtGrid g = *b.grid;
     if (g.n_refs > b.ref_cap) {              // cannot scatter: flag it and leave cell_count clear for the next build
-        if (i == 0) b.grid->overflow = 1;
-        for (uint32_t c = i; c < RT_MAX_CELLS; c += gridDim.x * blockDim.x) b.cell_count[c] = 0;
+        if (t == 0) b.grid->overflow = 1;
+        for (uint32_t c = t; c < RT_MAX_CELLS; c += gridDim.x * blockDim.x) b.cell_count[c] = 0;
         return;
     }
-    const bool valid = i < b.n_tris;
+    const bool valid = t < b.n_tris;
+    const uint32_t i = (valid && b.order) ? b.order[t] : t;
     int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
     if (valid) tri_voxel_range(b, g, i, vmin, vmax);
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
@@ -411,15 +413,16 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
 // ranking. The records of a voxel end up in the order the atomics hand the slots out (consecutive triangles of a
 // wavefront stay together, in descending index); the render kernel's nearest-hit update does not depend on it.
 __global__ void __launch_bounds__(256) k_scatter_emit(RtBuildDev b) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const RtGrid g = *b.grid;
     if (g.n_refs > b.ref_cap) {              // cannot scatter: flag it and leave cell_count clear for the next build
-        if (i == 0) b.grid->overflow = 1;
-        for (uint32_t c = i; c < RT_MAX_CELLS; c += gridDim.x * blockDim.x) b.cell_count[c] = 0;
+        if (t == 0) b.grid->overflow = 1;
+        for (uint32_t c = t; c < RT_MAX_CELLS; c += gridDim.x * blockDim.x) b.cell_count[c] = 0;
         return;
     }
-    const bool valid = i < b.n_tris;
+    const bool valid = t < b.n_tris;
+    const uint32_t i = (valid && b.order) ? b.order[t] : t;
     int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
     float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
     if (valid) {

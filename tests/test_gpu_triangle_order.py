@@ -1,0 +1,61 @@
+"""GPU: a large mesh whose file lists its triangles in arbitrary order. The grid build then visits the triangles along a
+space-filling curve (rt_scene_triangle_order), which no result may depend on: hit ids and colours against the oracle on the
+same shuffled triangle list (Serial/grid.h:118-150 appends in file order, Serial/geometry.h:162-175 updates in that order),
+the voxel lists read back in the reference's order, and both visiting orders against each other."""
+import numpy as np
+import pytest
+
+from conftest import BLUB, bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _shuffled(rt, k=3, seed=5):
+    tmp = rt.Scene(); tmp.load_mesh(BLUB)
+    v9 = rt.subdivide(tmp.triangles(), k); tmp.close()
+    return np.ascontiguousarray(v9[np.random.default_rng(seed).permutation(v9.shape[0])])
+
+
+def test_shuffled_mesh_is_built_in_spatial_order_with_the_oracles_results(rt, O, monkeypatch):
+    v9 = _shuffled(rt)                                           # 909,312 triangles: crowded voxels, run culling, index lists
+    W, H = 640, 360
+    o = O.OracleScene(); o.add_triangles(v9)
+    o_rgb, o_ids, _ = o.render(O.default_params(W, H, walk_mode=0))
+    assert int((o_ids >= 0).sum()) > 5000
+    frames = {}
+    for setting in ("", "0", "1"):
+        if setting:
+            monkeypatch.setenv("RT_TRI_ORDER", setting)
+        else:
+            monkeypatch.delenv("RT_TRI_ORDER", raising=False)
+        s = rt.Scene(); s.add_triangles(v9); s.upload()
+        area_file, area_sorted, _ = s.record_order()
+        area_spatial, spatial = s.triangle_order()
+        if setting == "":
+            # the file's order is incoherent: the build visits the triangles along the curve, whose runs are no wider
+            assert spatial and 0 < area_spatial < 1.1 * area_file
+        else:
+            assert spatial == (setting == "1")
+        rgb, _, ids = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL))
+        assert np.array_equal(ids, o_ids), "RT_TRI_ORDER=%r: hit ids differ from the oracle" % setting
+        assert np.array_equal(bits(rgb), bits(o_rgb)), "RT_TRI_ORDER=%r: colours differ from the oracle" % setting
+        rgb_e, _, ids_e = s.render(rt.default_params(W, H, walk_mode=rt.RT_WALK_EARLY))
+        assert int((ids_e != o_ids).sum()) <= 4
+        frames[setting] = (ids_e, rgb_e)
+        if setting == "":
+            start, tris = s.grid_csr()
+            o_start, o_tris = o.grid_csr()
+            assert np.array_equal(start, o_start) and np.array_equal(tris, o_tris)
+        s.close()
+    for setting in ("0", "1"):
+        assert np.array_equal(frames[setting][0], frames[""][0]) and np.array_equal(bits(frames[setting][1]), bits(frames[""][1]))
+
+
+def test_coherent_file_keeps_its_order(rt):
+    tmp = rt.Scene(); tmp.load_mesh(BLUB)
+    v9 = rt.subdivide(tmp.triangles(), 3); tmp.close()
+    s = rt.Scene(); s.add_triangles(v9); s.upload()
+    area_file, _, _ = s.record_order()
+    area_spatial, spatial = s.triangle_order()
+    assert area_spatial > 0 and not spatial and area_spatial >= 0.9 * area_file
+    s.close()
