@@ -790,7 +790,8 @@ extern "C" int rt_scene_upload(rt_scene* s) {
     s->use_order = false;
     if (T > 65536) {
         std::vector<uint32_t> order;
-        scene_spatial_order(s->tri, T, order, s->order_adjacent);
+        try { scene_spatial_order(s->tri, T, order, s->order_adjacent); }
+        catch (...) { return set_err(RT_ERR_NOMEM, "out of host memory while ordering %zu triangles", T); }     // no C++ exception crosses the C boundary
         if ((rc = s->tri_order.ensure(T))) return rc;
         HIP_TRY(hipMemcpy(s->tri_order.p, order.data(), T * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
