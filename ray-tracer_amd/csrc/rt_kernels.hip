@@ -227,6 +227,8 @@ __device__ __forceinline__ void tri_voxel_range(const RtBuildDev& b, const RtGri
 // The first RT_GROUP_TRIPS distinct voxels of the wavefront are grouped exactly (one trip each); with coherent meshes
 // that covers the wavefront. Lanes left over when every lane names another voxel (large triangles) stay on their own.
 #define RT_GROUP_TRIPS 8
+// thread-per-triangle build kernels: a triangle whose box covers more voxels than this is handled by the whole wavefront
+#define RT_BIG_RANGE 32
 __device__ __forceinline__ void lane_groups(bool act, int c, int lane, int& head, uint32_t& rank, uint32_t& size) {
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     head = lane; rank = 0; size = 1;
@@ -255,7 +257,11 @@ __global__ void __launch_bounds__(256) k_count(RtBuildDev b) {
     if (valid) tri_voxel_range(b, g, i, vmin, vmax);
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
-    const int n = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
+    const int n_all = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
+    // a triangle with a large voxel range (a ground quad under a detailed mesh: thousands of voxels) would keep its
+    // wavefront in the loop below for as many rounds; those are left out here and shared out among the lanes afterwards
+    const bool big = n_all > RT_BIG_RANGE;
+    const int n = big ? 0 : n_all;
     int x = 0, y = 0, z = 0;
     for (int r = 0;; ++r) {
         const bool act = r < n;
@@ -265,6 +271,15 @@ __global__ void __launch_bounds__(256) k_count(RtBuildDev b) {
         int head; uint32_t rank, size;
         lane_groups(act, c, lane, head, rank, size);
         if (act && lane == head) atomicAdd(&b.cell_count[c], size);
+    }
+    for (unsigned long long bm = __ballot(big); bm; bm &= bm - 1) {
+        const int l = __ffsll((long long)bm) - 1;
+        const int x0 = __builtin_amdgcn_readlane(vmin[0], l), y0 = __builtin_amdgcn_readlane(vmin[1], l), z0 = __builtin_amdgcn_readlane(vmin[2], l);
+        const int bex = __builtin_amdgcn_readlane(ex, l), bexy = bex * __builtin_amdgcn_readlane(ey, l), bn = __builtin_amdgcn_readlane(n_all, l);
+        for (int r = lane; r < bn; r += 64) {
+            const int zz = r / bexy, q = r - zz * bexy, yy = q / bex, xx = q - yy * bex;
+            atomicAdd(&b.cell_count[(z0 + zz) * nxy + (y0 + yy) * nx + (x0 + xx)], 1u);
+        }
     }
 }
 
@@ -386,7 +401,9 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
     if (valid) tri_voxel_range(b, g, i, vmin, vmax);
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
-    const int n = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
+    const int n_all = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
+    const bool big = n_all > RT_BIG_RANGE;              // as in k_count
+    const int n = big ? 0 : n_all;
     int x = 0, y = 0, z = 0;
     for (int r = 0;; ++r) {
         const bool act = r < n;
@@ -403,6 +420,19 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
         if (act) {
             const uint32_t pos = start + old - 1u - rank;
             b.ref_tri[pos] = i;
+            b.ref_cell[pos] = (uint32_t)c;
+        }
+    }
+    for (unsigned long long bm = __ballot(big); bm; bm &= bm - 1) {
+        const int l = __ffsll((long long)bm) - 1;
+        const uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)i, l);
+        const int x0 = __builtin_amdgcn_readlane(vmin[0], l), y0 = __builtin_amdgcn_readlane(vmin[1], l), z0 = __builtin_amdgcn_readlane(vmin[2], l);
+        const int bex = __builtin_amdgcn_readlane(ex, l), bexy = bex * __builtin_amdgcn_readlane(ey, l), bn = __builtin_amdgcn_readlane(n_all, l);
+        for (int r = lane; r < bn; r += 64) {
+            const int zz = r / bexy, q = r - zz * bexy, yy = q / bex, xx = q - yy * bex;
+            const int c = (z0 + zz) * nxy + (y0 + yy) * nx + (x0 + xx);
+            const uint32_t pos = b.cell_start[c] + atomicSub(&b.cell_count[c], 1u) - 1u;
+            b.ref_tri[pos] = bi;
             b.ref_cell[pos] = (uint32_t)c;
         }
     }
@@ -434,7 +464,9 @@ __global__ void __launch_bounds__(256) k_scatter_emit(RtBuildDev b) {
     }
     const int nx = g.n[0], nxy = g.n[0] * g.n[1];
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
-    const int n = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
+    const int n_all = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
+    const bool big = n_all > RT_BIG_RANGE;              // as in k_count
+    const int n = big ? 0 : n_all;
     int x = 0, y = 0, z = 0;
     for (int r = 0;; ++r) {
         const bool act = r < n;
@@ -454,6 +486,25 @@ __global__ void __launch_bounds__(256) k_scatter_emit(RtBuildDev b) {
             } else {
                 float4* o = b.recs + 3ull * (start + old - 1u - rank);
                 o[0] = rec0; o[1] = rec1; o[2] = rec2;
+            }
+        }
+    }
+    for (unsigned long long bm = __ballot(big); bm; bm &= bm - 1) {
+        const int l = __ffsll((long long)bm) - 1;
+        const uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)i, l);
+        const int x0 = __builtin_amdgcn_readlane(vmin[0], l), y0 = __builtin_amdgcn_readlane(vmin[1], l), z0 = __builtin_amdgcn_readlane(vmin[2], l);
+        const int bex = __builtin_amdgcn_readlane(ex, l), bexy = bex * __builtin_amdgcn_readlane(ey, l), bn = __builtin_amdgcn_readlane(n_all, l);
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+        if (!b.indexed) { const float4* r = b.tri_rec + 3ull * bi; q0 = r[0]; q1 = r[1]; q2 = r[2]; }
+        for (int r = lane; r < bn; r += 64) {
+            const int zz = r / bexy, q = r - zz * bexy, yy = q / bex, xx = q - yy * bex;
+            const int c = (z0 + zz) * nxy + (y0 + yy) * nx + (x0 + xx);
+            const uint32_t pos = b.cell_start[c] + atomicSub(&b.cell_count[c], 1u) - 1u;
+            if (b.indexed) {
+                reinterpret_cast<uint32_t*>(b.recs)[pos] = bi;
+            } else {
+                float4* o = b.recs + 3ull * pos;
+                o[0] = q0; o[1] = q1; o[2] = q2;
             }
         }
     }
