@@ -10,8 +10,14 @@
 #define RT_MAX_SCAN_BLOCKS (RT_MAX_CELLS / RT_SCAN_CHUNK)
 #define RT_WORK_LIST_COUNTS 32                     // first work[] word of the per-list tile counts (128 bytes after the head)
 #define RT_COST_SUM_PARTS 32u                       // partial sums of the cost estimate (power of two)
-#define RT_COUNTER_WORDS 88                        // 24 frame counters, 32 work-list words (64 x u32), 32 partial sums of the cost estimate
+#define RT_COUNTER_WORDS 216                       // 24 frame counters, 32 work-list words (64 x u32), 32 partial sums of the cost estimate, 8 x 16 for the dequeue heads (a cache line each)
 #define RT_COUNTER_FEEDBACK 20                     // frame counter the render kernel adds its streamed runs (low half) and hit trips (high half) to
+#ifndef RT_QUEUE_HEADS
+#define RT_QUEUE_HEADS 8u                          // dequeue heads of the trace kernel's queue, one per XCD (a power of two)
+#endif
+#define RT_WORK_HEADS 128                          // first work[] word of the dequeue heads (behind the partial sums), one every
+#define RT_WORK_HEAD_STRIDE 32                     // 128 bytes: atomics on one cache line are served one after the other
+#define RT_GETREG_XCC_ID ((3 << 11) | 20)          // s_getreg_b32 operand: hardware register 20 (XCC_ID), bits 0..3
 #define RT_QUEUE_LISTS 16                          // tile lists the trace kernel serves in order (cost classes)
 
 // Grid description, resident in device memory: k_grid_setup writes the geometry, k_scan_apply writes n_refs.
@@ -89,7 +95,7 @@ struct RtOutputs {
 
 // Per-frame work list of the render kernels.
 struct RtRenderWork {
-    uint32_t* work;               // [0] listed tiles, [1] dequeue head, [RT_WORK_LIST_COUNTS..+15] tiles per queue list, [+16..+31] unit shift per list; zeroed before each frame
+    uint32_t* work;               // [0] listed tiles, [RT_WORK_HEADS..+7] dequeue heads, [RT_WORK_LIST_COUNTS..+15] tiles per queue list, [+16..+31] unit shift per list; zeroed before each frame
     uint32_t* tile_list;          // capacity = tiles of the frame
     uint32_t* cost;               // estimated cost per listed tile
     uint32_t* est_by_tile;        // diagnostics: the four estimate features, each indexed by tile of the frame (may be NULL)
@@ -154,7 +160,7 @@ constexpr RtNoallocLayout rt_noalloc_layout() {
     L.occupancy = o; o += rt_align256(((size_t)RT_MAX_CELLS / 32 + 2) * sizeof(uint32_t));
     L.recs = o; o += rt_align256((size_t)RT_NOALLOC_MAX_REFS * 3 * sizeof(float4));
     L.blk_bounds = o; o += rt_align256(((size_t)RT_NOALLOC_MAX_REFS / 64 + 2) * 3 * sizeof(float4));
-    L.counters = o; o += rt_align256(88 * sizeof(unsigned long long));
+    L.counters = o; o += rt_align256(RT_COUNTER_WORDS * sizeof(unsigned long long));
     L.tile_list = o; o += rt_align256((size_t)RT_NOALLOC_MAX_TILES * sizeof(uint32_t));
     L.tile_cost = o; o += rt_align256((size_t)RT_NOALLOC_MAX_TILES * sizeof(uint32_t));
     L.queue_lists = o; o += rt_align256((size_t)RT_NOALLOC_MAX_TILES * RT_QUEUE_LISTS * sizeof(uint32_t));

@@ -877,7 +877,7 @@ __global__ void k_counters_reset(unsigned long long* counters, unsigned long lon
 }
 
 hipError_t rt_launch_counters_reset(unsigned long long* counters, unsigned long long* feedback, hipStream_t st) {
-    k_counters_reset<<<1, 128, 0, st>>>(counters, feedback);
+    k_counters_reset<<<1, 256, 0, st>>>(counters, feedback);
     return hipGetLastError();
 }
 
@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void write_pixel(const RtFrame& f, const RtOutputs& o
     }
 }
 
-// work[0] = number of listed tiles, work[1] = dequeue head; both zeroed by the host before each frame.
+// work[0] = number of listed tiles, work[RT_WORK_HEADS..+7] = dequeue heads; zeroed before each frame.
 // Runs over the tile rectangle [tx0, tx0+ntx) x [tb0, tb0+ntb) (tile columns x local bands) that can contain rays
 // entering the grid; the host has cleared the outputs to the background, so tiles that are not listed need no write.
 // tiles per wavefront: 16 on large frames (fewer atomics), 4 on small ones (shorter chains per wavefront)
@@ -1215,7 +1215,7 @@ __device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* 
 // weighted sum of the four numbers. Tiles whose rays graze the surface or cross crowded voxels get a large estimate;
 // they are queued first and cut into smaller work units (k_bucket), so the longest-running units start early and the
 // frame does not end on a single wavefront.
-// work[] words: [0] listed tiles, [1] dequeue head; tiles per queue list from RT_WORK_LIST_COUNTS on, in another cache
+// work[] words: [0] listed tiles, [RT_WORK_HEADS..+7] dequeue heads; tiles per queue list from RT_WORK_LIST_COUNTS on, in another cache
 // line than the dequeue head: every dequeue reads them, and loads from the line all wavefronts hit with atomics queue up.
 #define RT_EST_CELLS 28          // occupied voxels noted per estimate ray (LDS: 4 bytes x 256 lanes each)
 
@@ -2251,6 +2251,11 @@ __device__ __forceinline__ void trace_unit_parallel(const RtSceneDev& s, const R
     out_r = Rr; out_g = Rg; out_b = Rb;
 }
 
+// First tile of part q (0..RT_QUEUE_HEADS) when a list of n tiles is cut into RT_QUEUE_HEADS contiguous parts.
+__device__ __forceinline__ uint32_t queue_part(uint32_t n, uint32_t q) {
+    return (n * q) / RT_QUEUE_HEADS;                  // n < 2^21 tiles (RT_MAX_TILES), q <= 8
+}
+
 template <bool COUNT, bool OWN, int MODE = 0, int IDX = 2, bool DEFER = false>
 // Four blocks per CU (128 VGPRs, a few of them spilled) for the streamed path of crowded grids; three (144 VGPRs, nothing
 // spilled) for the variants that also hold the small-voxel loop, whose frames are bound by the longest chain of one wavefront
@@ -2288,6 +2293,16 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
     unsigned long long acc_ray[6] = {0, 0, 0, 0, 0, 0}, acc_w[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_cyc = 0, max_rounds = 0;
     const long long wave_t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
     uint32_t slot_next = 0;
+    // The queue has one head per XCD, each in a cache line of its own: atomics on one line are served one after the
+    // other, about 7 ns each, and with a single head for the 4096 wavefronts of a launch that queue of atomics, not the
+    // rays, set the pace of frames with short units. Every list is cut into eight contiguous parts (whole tiles); the
+    // wavefronts of an XCD serve their part of every list, list after list. A wavefront whose head has run past its end
+    // looks at all eight heads at once (plain loads) and goes on to the next one that still has units, or leaves. A list
+    // is in screen order, so the tiles an XCD works on at one time are neighbours that stream the same record runs through
+    // that XCD's L2. Which XCD a wavefront runs on is read from the hardware; any value 0..7 gives the same frame.
+    // The head a wavefront draws from lives in LDS, not in a register: the loop below has no scalar register to spare.
+    __shared__ uint32_t wave_head[RT_WAVES_PER_BLOCK];
+    if (!DEFER && lane == 0) wave_head[threadIdx.x >> 6] = ((uint32_t)__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u) % RT_QUEUE_HEADS;
     for (;;) {
         asm volatile("" ::: "memory");
         const RtSceneDev& s = A->s;
@@ -2295,11 +2310,17 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
         const RtShade& sh = A->sh;
         const RtFrame& f = A->f;
         const RtOutputs& o = A->o;
+        // The variant for frames full of hits keeps to one head: its loops are the shortest of registers, the code of the
+        // eight heads costs them spills (measured: the 4K plane frame 6 % slower with four frames in flight), and its units
+        // are long, so its atomics are far apart anyway.
+        const uint32_t head = DEFER ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_head[threadIdx.x >> 6]);
         // units per list (lane k < 16 looks after list k), requested before the atomic so that both round trips overlap
         const uint32_t my_shift = (lane < RT_QUEUE_LISTS) ? work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + lane] : 0u;
-        const uint32_t my_units = (lane < RT_QUEUE_LISTS) ? (work[RT_WORK_LIST_COUNTS + lane] << my_shift) : 0u;
-        if (lane == 0) slot_next = atomicAdd(&work[1], 1u);
+        const uint32_t my_tiles = (lane < RT_QUEUE_LISTS) ? work[RT_WORK_LIST_COUNTS + lane] : 0u;
+        if (lane == 0) slot_next = atomicAdd(&work[RT_WORK_HEADS + RT_WORK_HEAD_STRIDE * head], 1u);
         const uint32_t slot = __builtin_amdgcn_readfirstlane(slot_next);
+        const uint32_t my_t0 = DEFER ? 0u : queue_part(my_tiles, head);  // this head's tiles of the list: [my_t0, my_t1)
+        const uint32_t my_units = ((DEFER ? my_tiles : queue_part(my_tiles, head + 1u)) - my_t0) << my_shift;
         uint32_t my_end = my_units;
 #pragma unroll
         for (int off = 1; off < RT_QUEUE_LISTS; off <<= 1) {
@@ -2307,12 +2328,44 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
             if (lane >= off) my_end += v;
         }
         const unsigned long long owner = __ballot(lane < RT_QUEUE_LISTS && slot < my_end);
-        if (!owner) break;                                  // the queue is empty
+        if (!owner) {                                       // this head is past its end
+            if constexpr (DEFER) break;
+            // lane = (head q, lists j and j + 8): the units of head q, summed over the eight lanes of q, against its counter
+            const uint32_t q = (uint32_t)lane >> 3, j = (uint32_t)lane & 7u;
+            const uint32_t ta = work[RT_WORK_LIST_COUNTS + j], tb = work[RT_WORK_LIST_COUNTS + 8u + j];
+            const uint32_t sa = work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + j], sb = work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + 8u + j];
+            uint32_t u = ((queue_part(ta, q + 1u) - queue_part(ta, q)) << sa) + ((queue_part(tb, q + 1u) - queue_part(tb, q)) << sb);
+            u += __shfl_xor(u, 1); u += __shfl_xor(u, 2); u += __shfl_xor(u, 4);
+            const uint32_t drawn = __hip_atomic_load(&work[RT_WORK_HEADS + RT_WORK_HEAD_STRIDE * (q % RT_QUEUE_HEADS)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long has = __ballot(j == 0u && q < RT_QUEUE_HEADS && drawn < u);          // bit 8 q
+            uint32_t live = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < RT_QUEUE_HEADS; ++k) live |= (uint32_t)((has >> (8u * k)) & 1ull) << k;
+            // the load above comes after this wavefront's own atomic on `head` and reads the same location: it shows `head`
+            // as used up, and so every head a wavefront has drawn from in vain; the bit is cleared all the same
+            live &= ~(1u << head);
+            if (!live) break;                               // the queue is empty
+            const uint32_t ahead = ((live | (live << RT_QUEUE_HEADS)) >> (head + 1u)) & ((1u << RT_QUEUE_HEADS) - 1u);
+            if (lane == 0) wave_head[threadIdx.x >> 6] = (head + 1u + (uint32_t)__builtin_ctz(ahead)) % RT_QUEUE_HEADS;
+            continue;
+        }
         const int li = __ffsll((long long)owner) - 1;
         const int ushift = __builtin_amdgcn_readlane((int)my_shift, li);
         const uint32_t rel = slot - (uint32_t)__builtin_amdgcn_readlane((int)(my_end - my_units), li);
-        const int tile = (int)A->lists[(size_t)li * A->list_cap + (rel >> ushift)];
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)my_t0, li);
+        const int tile = (int)A->lists[(size_t)li * A->list_cap + t0 + (rel >> ushift)];
         const int sub = (int)(rel & ((1u << ushift) - 1u));
+        uint32_t uslot = 0;                                 // counting build: the unit's number in the order of the lists
+        if constexpr (COUNT) {
+            const uint32_t all_units = my_tiles << my_shift;
+            uint32_t all_end = all_units;
+#pragma unroll
+            for (int off = 1; off < RT_QUEUE_LISTS; off <<= 1) {
+                const uint32_t v = __shfl_up(all_end, off);
+                if (lane >= off) all_end += v;
+            }
+            uslot = (uint32_t)__builtin_amdgcn_readlane((int)(all_end - all_units), li) + (t0 << ushift) + rel;
+        }
         // lane -> pixel of the tile: the tile's 64 pixels are numbered along a Z-order curve and unit `sub` owns
         // 64 >> ushift consecutive ones (a compact 8x8, 8x4, 4x4, 4x2 ... block); the other lanes carry no ray
         const int per_unit = 64 >> ushift;
@@ -2403,20 +2456,20 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
                 if (cyc > max_cyc) max_cyc = cyc;
                 if (wp.rounds + ws.rounds > max_rounds) max_rounds = wp.rounds + ws.rounds;
                 if (lane == 0 && o.unit_cost) {
-                    o.unit_cost[slot] = (uint32_t)cyc; atomicAdd(&o.tile_cycles[tile], (uint32_t)cyc);
-                    o.unit_info[slot] = (uint32_t)tile | ((uint32_t)ushift << 24) | ((uint32_t)li << 28);
+                    o.unit_cost[uslot] = (uint32_t)cyc; atomicAdd(&o.tile_cycles[tile], (uint32_t)cyc);
+                    o.unit_info[uslot] = (uint32_t)tile | ((uint32_t)ushift << 24) | ((uint32_t)li << 28);
                     // (run, ray) test iterations and record runs streamed by the unit, 18 + 14 bits, saturating
                     const uint32_t ut = wp.trips + ws.trips, ui = wp.items + ws.items;
                     const size_t n16 = (size_t)16 * ((f.width + RT_TILE - 1) / RT_TILE) * ((f.out_rows + RT_TILE - 1) / RT_TILE);
-                    o.unit_info[n16 + slot] = (ut > 0x3ffffu ? 0x3ffffu : ut) | ((ui > 0x3fffu ? 0x3fffu : ui) << 18);
+                    o.unit_info[n16 + uslot] = (ut > 0x3ffffu ? 0x3ffffu : ut) | ((ui > 0x3fffu ? 0x3fffu : ui) << 18);
                     // cycles of the three phases in units of 256, and the rounds
                     const uint32_t c_s = (wp.cyc_step + ws.cyc_step) >> 8, c_c = (wp.cyc_cull + ws.cyc_cull) >> 8, c_t = (wp.cyc_test + ws.cyc_test) >> 8;
-                    o.unit_info[2 * n16 + slot] = (c_s > 0xffffu ? 0xffffu : c_s) | ((c_c > 0xffffu ? 0xffffu : c_c) << 16);
+                    o.unit_info[2 * n16 + uslot] = (c_s > 0xffffu ? 0xffffu : c_s) | ((c_c > 0xffffu ? 0xffffu : c_c) << 16);
                     // start and duration on the 100 MHz real-time clock (the shader clock is not the same on all dies):
                     // start in the low 20 bits, duration / 64 above, saturating
                     const uint32_t rt_dur = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt_start) >> 6;
-                    o.unit_info[4 * n16 + slot] = ((uint32_t)rt_start & 0xfffffu) | ((rt_dur > 0xfffu ? 0xfffu : rt_dur) << 20);
-                    o.unit_info[3 * n16 + slot] = (c_t > 0xffffffu ? 0xffffffu : c_t) | ((wp.rounds + ws.rounds > 255u ? 255u : wp.rounds + ws.rounds) << 24);
+                    o.unit_info[4 * n16 + uslot] = ((uint32_t)rt_start & 0xfffffu) | ((rt_dur > 0xfffu ? 0xfffu : rt_dur) << 20);
+                    o.unit_info[3 * n16 + uslot] = (c_t > 0xffffffu ? 0xffffffu : c_t) | ((wp.rounds + ws.rounds > 255u ? 255u : wp.rounds + ws.rounds) << 24);
                 }
             }
         }
