@@ -1714,20 +1714,26 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             if (__popcll(om) >= RT_OWN_MIN_RAYS) {
                 un &= ~om;
                 uint32_t own_tests = 0;
-                if (ray_lanes <= 32) {
-                    // A unit of 32 rays or fewer leaves lanes without a ray: lane g * ray_lanes + r helps ray r and takes
-                    // every G-th record of its voxel (G = 2 or 4 lanes per ray). The passing triangles of a step are then
-                    // applied by the ray's own lane in ascending record order, which is the reference's order.
-                    const int lg = __ffs(ray_lanes) - 1;
-                    const int G = ray_lanes <= 16 ? 4 : 2;
-                    const int r = lane & (ray_lanes - 1), g = lane >> lg;
-                    const bool helper = g < G;
-                    bool own_r = __shfl((int)own, r) != 0 && helper;
+                {
+                    // The M rays of the round that stand in such voxels are numbered (ray j = the j-th of them) and share
+                    // the 64 lanes: lane g * 2^lg + j helps ray j and takes every G-th record of its voxel, G = 64 >> lg
+                    // lanes per ray with 2^lg the power of two from M on. The passing triangles of a step are then applied
+                    // by the ray's own lane in ascending record order, which is the reference's order.
+                    const int M = __popcll(om);
+                    const int lg = M <= 4 ? 2 : (M <= 8 ? 3 : (M <= 16 ? 4 : (M <= 32 ? 5 : 6)));
+                    const int G = 64 >> lg;
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    // place of this lane when the rays in small voxels come first: a permutation of the 64 lanes
+                    const int place = own ? __popcll(om & below) : M + __popcll(~om & below);
+                    const int by_place = __builtin_amdgcn_ds_permute(place << 2, lane);     // lane `place` receives this lane's number
+                    const int j = lane & ((1 << lg) - 1), g = lane >> lg;
+                    const int r = __shfl(by_place, j);                                      // the lane that holds ray j
+                    bool own_r = j < M;
                     const uint32_t cb = (uint32_t)__shfl((int)cbeg, r), ce = (uint32_t)__shfl((int)cend, r);
                     const float rox = SHARED_ORIGIN ? ox : __shfl(ox, r), roy = SHARED_ORIGIN ? oy : __shfl(oy, r), roz = SHARED_ORIGIN ? oz : __shfl(oz, r);
                     const double rdx = (double)__shfl(dx, r), rdy = (double)__shfl(dy, r), rdz = (double)__shfl(dz, r);
-                    for (uint32_t base = cb; __ballot(own_r && base < ce); base += (uint32_t)G) {
-                        const uint32_t p = base + (uint32_t)g;
+                    for (uint32_t k = 0; __ballot(own_r && cb + k < ce); k += (uint32_t)G) {
+                        const uint32_t p = cb + k + (uint32_t)g;
                         int pass_id = -1;                       // record index of a passing triangle
                         double t_p = 0.0;
                         if (own_r && p < ce) {
@@ -1756,57 +1762,26 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                             }
                         }
                         if (__ballot(pass_id >= 0)) {
-                            bool stop = false;
+                            bool stop = false;                  // own lane of a ray: a shadow ray has met a triangle
                             for (int gg = 0; gg < G; ++gg) {
-                                const int src = (gg << lg) + r;
+                                const int src = ((gg << lg) + place) & 63;          // own lanes: place < M <= 2^lg
                                 const int id_g = __shfl(pass_id, src);
                                 if (ANY_HIT) {
-                                    if (id_g >= 0 && !stop) {
+                                    if (id_g >= 0 && !stop && own) {
                                         stop = true;
-                                        if (g == 0 && own) {
-                                            hit = true; alive = false;
-                                            if (COUNT) wc.tests -= ce - (base + (uint32_t)gg + 1u);   // tests the reference order skips
-                                        }
+                                        hit = true; alive = false;
+                                        if (COUNT) wc.tests -= cend - (cbeg + k + (uint32_t)gg + 1u);   // tests the reference order skips
                                     }
                                 } else {
                                     const double t_g = __shfl(t_p, src);
-                                    if (id_g >= 0 && g == 0 && own) {
+                                    if (id_g >= 0 && own) {
                                         hit = true;
                                         if (!use_eps || t_g > (double)eps) vb_add(vb, t_g, id_g);
                                     }
                                 }
                             }
-                            if (ANY_HIT && stop) own_r = false;
+                            if (ANY_HIT && __shfl((int)stop, r) != 0) own_r = false;        // its helpers stop with it
                         }
-                    }
-                } else if (own) {
-                    for (uint32_t p = cbeg; p < cend; ++p) {
-                        const float4* r = RT_REC_PTR(s, p);
-                        const TriRec t = unpack_rec(r[0], r[1], r[2]);
-                        if (COUNT) ++own_tests;
-                        const double sx = t.v0x - ox, sy = t.v0y - oy, sz = t.v0z - oz;          // float subtractions, then widened
-                        const double p_e2s = minor_f32(t.e2y, sz, sy, t.e2z);
-                        const double p_e1s = minor_f32(t.e1y, sz, sy, t.e1z);
-                        const double p_e2d = minor_f32(t.e2y, ddz, ddy, t.e2z);
-                        const double p_e1d = minor_f32(t.e1y, ddz, ddy, t.e1z);
-                        const double p_sd = minor_f32(sy, ddz, ddy, sz);
-                        const double A = t.e1x * p_e2d - t.e2x * p_e1d + ddx * t.m12;
-                        const double bnum = sx * p_e2d - t.e2x * p_sd - ddx * p_e2s;
-                        const double gnum = t.e1x * p_sd - sx * p_e1d + ddx * p_e1s;
-                        const int ha = __double2hiint(A), hb = __double2hiint(bnum), hg = __double2hiint(gnum);
-                        if (((ha ^ hb) | (ha ^ hg)) < 0) continue;                               // signs differ: beta or gamma <= 0
-                        if (fabs(bnum + gnum) > fabs(A) * (1.0 + 1e-12)) continue;               // beta + gamma >= 1 beyond any rounding
-                        const double beta = bnum / A, gamma = gnum / A;
-                        if (!(beta > 0.0 && gamma > 0.0 && beta + gamma < 1.0)) continue;
-                        hit = true;
-                        if (ANY_HIT) {
-                            alive = false;
-                            if (COUNT) wc.tests -= cend - (p + 1u);                              // tests the reference order skips
-                            break;
-                        }
-                        const double tnum = t.e1x * p_e2s - t.e2x * p_e1s + sx * t.m12;
-                        const double t_p = tnum / A;
-                        if (!use_eps || t_p > (double)eps) vb_add(vb, t_p, (int)t.id);
                     }
                 }
                 if (COUNT) {                     // tests executed: a wavefront-wide number like the streamed runs' lanes
