@@ -1527,12 +1527,12 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 #ifndef RT_STEPS_PER_ROUND
 #define RT_STEPS_PER_ROUND 8
 #endif
-// voxels of up to this many records are tested by the rays standing in them (lane = ray) when at least
-// RT_OWN_MIN_RAYS rays of the wavefront stand in such voxels; 0 switches the path off
+// voxels of up to this many records are tested apart from the streamed runs, by the lanes dealt to the rays standing in
+// them, when at least RT_OWN_MIN_RAYS rays of the wavefront stand in such voxels; 0 switches the path off
 #ifndef RT_OWN_MAX_RECORDS
 #define RT_OWN_MAX_RECORDS 8
 #endif
-// the same limit for units of 32 rays or fewer, where the idle lanes share the records of a voxel out
+// the same limit for units of 32 rays or fewer (never more than 32 such rays: at least two lanes each)
 #ifndef RT_OWN_MAX_RECORDS_SHARED
 #define RT_OWN_MAX_RECORDS_SHARED 24
 #endif
@@ -1706,8 +1706,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         }
         // ---- OWN: voxels with a handful of records, lane = ray. In a sparse scene the rays of a unit stand in dozens of
         // different voxels of a few triangles each; streamed as (voxel, run) items every one of them would cost a trip of
-        // the whole wavefront for a handful of busy lanes. Here every such ray reads the records of its own voxel and
-        // tests them itself, in ascending order (the reference's order), with the expressions of the TEST phase.
+        // the whole wavefront for a handful of busy lanes. Here the records of every such ray's voxel are tested by the
+        // lanes dealt to that ray and applied in ascending order (the reference's order), with the expressions of TEST.
         if (OWN && RT_OWN_MAX_RECORDS > 0) {
             const bool own = at_voxel && !cull && (cend - cbeg) <= (uint32_t)(ray_lanes <= 32 ? RT_OWN_MAX_RECORDS_SHARED : RT_OWN_MAX_RECORDS);
             const unsigned long long om = __ballot(own);
