@@ -95,7 +95,7 @@ struct RtOutputs {
 
 // Per-frame work list of the render kernels.
 struct RtRenderWork {
-    uint32_t* work;               // [0] listed tiles, [RT_WORK_HEADS..+7] dequeue heads, [RT_WORK_LIST_COUNTS..+15] tiles per queue list, [+16..+31] unit shift per list; zeroed before each frame
+    uint32_t* work;               // [0] listed tiles, [RT_WORK_HEADS + RT_WORK_HEAD_STRIDE * q] dequeue head q, [RT_WORK_LIST_COUNTS..+15] tiles per queue list, [+16..+31] unit shift per list; zeroed before each frame
     uint32_t* tile_list;          // capacity = tiles of the frame
     uint32_t* cost;               // estimated cost per listed tile
     uint32_t* est_by_tile;        // diagnostics: the four estimate features, each indexed by tile of the frame (may be NULL)

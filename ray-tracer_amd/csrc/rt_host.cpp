@@ -82,7 +82,7 @@ struct WorkSet {
     DevBuf<uint32_t> bounds_enc, cell_count, cell_start, block_sums, occupancy, ref_tri, ref_cell;
     DevBuf<uint2> row_minmax;
     DevBuf<float4> recs, blk_bounds;
-    DevBuf<unsigned long long> counters;   // 24 frame counters, the work-list words (RtRenderWork::work, 32 of them), 32 partial sums of the cost estimate
+    DevBuf<unsigned long long> counters;   // 24 frame counters, the work-list words (RtRenderWork::work, 32 of them), 32 partial sums of the cost estimate, the dequeue heads
     DevBuf<uint32_t> tile_list, unit_cost, tile_cost, queue_lists;
     bool zeroed = false;               // the fixed-size tables exist and were cleared for the current triangle list
     bool grid_valid = false;

@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void write_pixel(const RtFrame& f, const RtOutputs& o
     }
 }
 
-// work[0] = number of listed tiles, work[RT_WORK_HEADS..+7] = dequeue heads; zeroed before each frame.
+// work[0] = number of listed tiles, work[RT_WORK_HEADS + RT_WORK_HEAD_STRIDE * q] = dequeue head q; zeroed before each frame.
 // Runs over the tile rectangle [tx0, tx0+ntx) x [tb0, tb0+ntb) (tile columns x local bands) that can contain rays
 // entering the grid; the host has cleared the outputs to the background, so tiles that are not listed need no write.
 // tiles per wavefront: 16 on large frames (fewer atomics), 4 on small ones (shorter chains per wavefront)
@@ -1215,7 +1215,7 @@ __device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* 
 // weighted sum of the four numbers. Tiles whose rays graze the surface or cross crowded voxels get a large estimate;
 // they are queued first and cut into smaller work units (k_bucket), so the longest-running units start early and the
 // frame does not end on a single wavefront.
-// work[] words: [0] listed tiles, [RT_WORK_HEADS..+7] dequeue heads; tiles per queue list from RT_WORK_LIST_COUNTS on, in another cache
+// work[] words: [0] listed tiles, [RT_WORK_HEADS + RT_WORK_HEAD_STRIDE * q] dequeue head q; tiles per queue list from RT_WORK_LIST_COUNTS on, in another cache
 // line than the dequeue head: every dequeue reads them, and loads from the line all wavefronts hit with atomics queue up.
 #define RT_EST_CELLS 28          // occupied voxels noted per estimate ray (LDS: 4 bytes x 256 lanes each)
 
