@@ -50,6 +50,16 @@ int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out);
  * No counterpart in the reference. */
 int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n);
 
+/* Loop counts of the counting frames rendered on the current device since the last reset: how often the wavefronts of the
+ * trace kernel went through each loop of the walk, 18 numbers for the primary walks, then the same 18 for the shadow walks,
+ * in this order: rounds with a ray at an occupied voxel, rounds whose first voxel step ran, iterations of the empty-voxel
+ * loop, rounds with lane = ray run culling, its iterations, the (ray, run) box tests in them, voxels culled lane = run,
+ * rays broadcast there, item generator calls, its loop iterations, voxels it opened, items tested, items with a live ray,
+ * (run, ray) trips, trips with a candidate triangle, trips with a passing triangle, passing triangles applied, walks.
+ * Multiplied with the instructions of each loop body (tools/isa_attrib.py) they say where the kernel's instructions go.
+ * Synchronises the device. No counterpart in the reference. */
+int rt_loop_counts(uint64_t* out, int32_t n, int32_t reset);
+
 /* What the render kernel of an earlier frame of the scene reported about its triangle tests: record runs streamed and
  * (run, ray) trips that found a candidate triangle, and whether the next frame would take the kernel variant that finishes
  * a run's hit trips together (it does from 12 such trips per run on; RT_DEFER=0/1 in the environment forces it). The

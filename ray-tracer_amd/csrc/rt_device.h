@@ -183,6 +183,7 @@ hipError_t rt_launch_trace(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, Rt
 size_t rt_trace_lds_bytes(int bitmap_words);
 hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32_t n_refs, int indexed, hipStream_t st);
 hipError_t rt_launch_probe_wait(unsigned long long* stamps, unsigned int ticks, hipStream_t st);   // stamps[0..1]: start and end on the 100 MHz clock
+hipError_t rt_read_loop_counts(unsigned long long* out, int n, int reset);   // loop counts of the counting frames since the last reset, current device
 hipError_t rt_launch_selftest_div(const double* num, const double* den, uint32_t n, uint32_t* mismatches, hipStream_t st);
 hipError_t rt_launch_deinterleave(const void* src, void* dst, int32_t width, int32_t height, int32_t part_count,
                                   int32_t part_rows, int32_t elem_bytes, hipStream_t st);

@@ -1395,6 +1395,15 @@ extern "C" int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out) {
     return RT_OK;
 }
 
+extern "C" int rt_loop_counts(uint64_t* out, int32_t n, int32_t reset) {
+    if (!out || n < 0) return set_err(RT_ERR_INVALID, "rt_loop_counts: bad argument");
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long tmp[64] = {};
+    HIP_TRY(rt_read_loop_counts(tmp, 64, reset));
+    for (int k = 0; k < n && k < 64; ++k) out[k] = tmp[k];
+    return RT_OK;
+}
+
 extern "C" int rt_deinterleave_device(const rt_params* p, const void* d_src, void* d_dst, int32_t elem_bytes, void* stream) {
     int rc = check_params(p);
     if (rc) return rc;

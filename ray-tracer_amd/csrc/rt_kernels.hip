@@ -971,19 +971,48 @@ __device__ __forceinline__ GridU load_grid(const RtGrid* gp) {
     return g;
 }
 
+// The `@phase NAME` comments from here on are read by tools/isa_attrib.py: the instructions generated from the lines after a
+// marker (up to the next one) are charged to NAME in the per-phase instruction counts of the trace kernel.
+// @phase other
 struct Nearest {             // the reference's two globals, per ray (Serial/geometry.h:10-11)
     float t;
     int id;
 };
 
+// Loop counts of wave_walk in the counting build, per wavefront: executions of a loop body or branch by the wavefront as a
+// whole. Multiplied with the instructions each body holds they say where the kernel's instructions go.
+enum {
+    RT_LOOP_ROUNDS_AT_VOXEL,  // rounds in which some ray stands at an occupied voxel (the others only step)
+    RT_LOOP_ADVANCE,          // rounds whose first, unconditional voxel step ran
+    RT_LOOP_STEP_ITER,        // iterations of the empty-voxel loop
+    RT_LOOP_CULL_A_ROUNDS,    // rounds with lane = ray culling
+    RT_LOOP_CULL_A_ITER,      // its iterations (runs of the most crowded voxel among the lanes)
+    RT_LOOP_CULL_A_LANES,     // (ray, run) box tests those iterations held
+    RT_LOOP_CULL_B_VOXELS,    // voxels culled lane = run
+    RT_LOOP_CULL_B_RAYS,      // rays broadcast there
+    RT_LOOP_ITEMGEN_CALLS,    // calls of the item generator
+    RT_LOOP_ITEMGEN_ITER,     // iterations of its loop
+    RT_LOOP_ITEMGEN_VOXELS,   // voxels it opened
+    RT_LOOP_ITEMS,            // items tested
+    RT_LOOP_ITEMS_WITH_RAYS,  // items with at least one live ray
+    RT_LOOP_TRIPS,            // (run, ray) trips
+    RT_LOOP_TRIPS_CAND,       // trips with a candidate triangle (divisions)
+    RT_LOOP_TRIPS_PASS,       // trips with a passing triangle
+    RT_LOOP_PASS_LANES,       // passing triangles applied to a ray's summary
+    RT_LOOP_WALKS,            // calls of wave_walk with a live ray
+    RT_LOOP_WORDS
+};
 struct WalkCount {           // work counters of one ray (only maintained by the counting build of the kernel)
     uint32_t entered, steps, tests;
     uint32_t rounds, slots, lanes;   // per wavefront (identical in every lane): scheduling rounds, voxel visits, triangle tests executed
     uint32_t cyc_step, cyc_test;     // shader cycles spent in the two phases
     uint32_t items, trips, cyc_cull; // record runs streamed, (run, ray) test iterations, cycles of the run culling
     uint32_t fb_items, fb_hits;      // kept by every build of the kernel: record runs streamed, (run, ray) trips with a candidate triangle
+    // counting build: how often the wavefront went through each loop of wave_walk (RT_LOOP_* below), whatever its lanes did
+    uint32_t loops[RT_LOOP_WORDS];
 };
 
+// @phase raygen
 // Primary ray of pixel (x, y), Serial/raytracer.cpp:153-161; xw and yw are evaluated in double.
 __device__ __forceinline__ void primary_ray(const RtCamera& cam, const RtFrame& f, int x, int y, float& dx, float& dy, float& dz) {
     dx = 0.f + (-cam.w[0]) * cam.focal_distance;
@@ -996,6 +1025,7 @@ __device__ __forceinline__ void primary_ray(const RtCamera& cam, const RtFrame& 
     normalize3(dx, dy, dz);
 }
 
+// @phase walk_setup
 // Entry of GridAccel::Intersect, Serial/grid.h:172-175: rayT = mint when ray(mint) is inside the bounds
 // (boundingBox::Inside, Serial/geometry.h:287-289), else the slab test's t0 (boundingBox::Intersect,
 // Serial/geometry.h:291-316), else the ray misses the grid.
@@ -1021,6 +1051,7 @@ __device__ __forceinline__ bool grid_entry(const GridU& g, float ox, float oy, f
     return ok;
 }
 
+// @phase raygen
 // Pixel of lane `lane` in tile `tile` of this part: x, the row inside the part's buffers, the row in the frame.
 __device__ __forceinline__ void tile_pixel(const RtFrame& f, int tile, int lane, int& x, int& y_local, int& y) {
     const int tiles_x = (f.width + RT_TILE - 1) / RT_TILE;
@@ -1030,6 +1061,7 @@ __device__ __forceinline__ void tile_pixel(const RtFrame& f, int tile, int lane,
     y = (band * f.part_count + f.part_index) * RT_TILE + (lane >> 3);
 }
 
+// @phase write
 __device__ __forceinline__ void write_pixel(const RtFrame& f, const RtOutputs& o, int x, int y_local, float cr, float cg, float cb, int id) {
     if (x < f.width && y_local < f.out_rows) {
         const size_t pix = (size_t)y_local * f.width + x;
@@ -1045,6 +1077,7 @@ __device__ __forceinline__ void write_pixel(const RtFrame& f, const RtOutputs& o
     }
 }
 
+// @phase other
 // work[0] = number of listed tiles, work[RT_WORK_HEADS + RT_WORK_HEAD_STRIDE * q] = dequeue head q; zeroed before each frame.
 // Runs over the tile rectangle [tx0, tx0+ntx) x [tb0, tb0+ntb) (tile columns x local bands) that can contain rays
 // entering the grid; the host has cleared the outputs to the background, so tiles that are not listed need no write.
@@ -1115,6 +1148,7 @@ __global__ void __launch_bounds__(256) k_classify(RtSceneDev s, RtCamera cam, Rt
     }
 }
 
+// @phase walk_setup
 // DDA state of one ray, Serial/grid.h:182-203. Pos/Step/Out of the reference are kept in an equivalent form:
 // the linear voxel index, its increment per axis and the number of steps left before the ray leaves the grid
 // along each axis (Pos == Out after left+1 steps).
@@ -1151,6 +1185,7 @@ __device__ __forceinline__ void dda_setup(Dda& w, const GridU& g, float ox, floa
     dda_axis(g, 2, g.n[0] * g.n[1], oz, dz, rayT, w.next2, w.delta2, w.left2, w.cstep2, w.cell);
 }
 
+// @phase step
 // One step of the walk loop, Serial/grid.h:216-227, plus the early-exit rule. Returns false when the ray is done.
 // stepAxis comes from the 3-bit compare table {2,1,2,1,2,2,0,0}: axis 0 iff next0 < next1 and next0 < next2,
 // axis 1 iff not (next0 < next1) and next1 < next2, else axis 2 (NaNs compare false in both forms). Written without
@@ -1193,6 +1228,7 @@ __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t
     return go;
 }
 
+// @phase kernel_setup
 // Occupancy bitmap of the grid into LDS, all loads of a thread in flight together (16 bytes each).
 __device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* occupancy, int words) {
     const int quads = words >> 2;
@@ -1209,6 +1245,7 @@ __device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* 
     __syncthreads();
 }
 
+// @phase other
 // COST ESTIMATE per listed tile, from the rays of four of its pixels and without any triangle test: each ray
 // is walked through the whole grid and the occupied voxels it meets and their triangle counts are summed; a stand-in
 // shadow ray, started where the primary ray enters its first occupied voxel, is walked the same way. The estimate is a
@@ -1414,6 +1451,7 @@ __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* 
     }
 }
 
+// @phase bcast
 __device__ __forceinline__ float bcast_f32(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
@@ -1429,6 +1467,7 @@ __device__ __forceinline__ double bcast_f64(double v, int src_lane) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// @phase trip
 // a*b - c*d for doubles that all hold float values: both products are exact in double (24 + 24 significant bits,
 // exponents far inside the range), so the reference's mul, mul, sub rounds once, in the subtraction, and a multiply
 // followed by one fused multiply-add rounds the same exact value once: identical bits, one instruction less.
@@ -1436,6 +1475,7 @@ __device__ __forceinline__ double minor_f32(double a, double b, double c, double
     return __builtin_fma(a, b, -(c * d));
 }
 
+// @phase resolve
 // Division with a shared reciprocal. The f64 division of this target is the sequence: scale both operands, v_rcp_f64
 // of the denominator, two Newton steps, quotient estimate, residual, one fused correction (+ post-scaling), fix-up of
 // special operands. When the biased exponents of numerator and denominator lie within 1023 +- 300 nothing is scaled and
@@ -1455,6 +1495,7 @@ __device__ __forceinline__ uint32_t exponent_field(double x) { return ((uint32_t
 #define RT_DIV_EXP_LO (1023u - 300u)
 #define RT_DIV_EXP_HI (1023u + 300u)
 
+// @phase other
 // Self-test of the shared-reciprocal division: count the pairs for which it differs from the plain division.
 __global__ void k_selftest_div(const double* __restrict__ num, const double* __restrict__ den, uint32_t n, uint32_t* mismatches) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1471,6 +1512,7 @@ hipError_t rt_launch_selftest_div(const double* num, const double* den, uint32_t
     return hipGetLastError();
 }
 
+// @phase resolve
 // Order-free form of the reference's nearest-hit update. Triangle::Intersect (Serial/geometry.h:162-175) compares the
 // double hit distance t_c of every passing triangle with the FLOAT global_t and stores (float)t_c, so the outcome of a
 // voxel's tests depends on their order (ascending triangle index, Serial/grid.h:24-29) through that rounding. The
@@ -1496,11 +1538,13 @@ __device__ __forceinline__ void vb_add(VoxelBest& v, double t, int id) {
     if (fj < v.f) { v.f = fj; v.j0 = (uint32_t)id; v.L = below; }
     else if (fj == v.f) { v.j0 = min(v.j0, (uint32_t)id); v.L = max(v.L, below); }
 }
+// @phase apply
 __device__ __forceinline__ void vb_apply(const VoxelBest& v, Nearest& st) {
     if (v.f < st.t) { st.t = v.f; st.id = (v.L >= 0) ? v.L : (int)v.j0; }
     else if (v.f == st.t && v.L >= 0) st.id = v.L;
 }
 
+// @phase item
 // One triangle record as a lane holds it during the test phase.
 struct TriRec {
     float v0x, v0y, v0z;
@@ -1519,6 +1563,7 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
     return t;
 }
 
+// @phase other
 // kernel variant DEFER: runs tested by at least this many rays resolve single-candidate trips together after the ray loop
 #ifndef RT_DEFER_MIN_RAYS
 #define RT_DEFER_MIN_RAYS 16
@@ -1587,9 +1632,11 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                                           bool early, float slack, uint32_t cull_min, int ray_lanes, Nearest& st, WalkCount& wc,
                                           double* td = nullptr) {
     static_assert(RULE == 0 || !OWN, "the Parallel tree's hit rule is only built into the streamed test path");
+    // @phase walk_setup
     Dda w;
     bool alive = false;
     if (__ballot(active)) {
+        if (COUNT) wc.loops[RT_LOOP_WALKS] += 1;
         const GridU g = load_grid(s.grid);          // only needed for the set-up of the walk
         if (active) {
         float rayT;
@@ -1604,9 +1651,11 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
     bool first = true;
     const double ddx = dx, ddy = dy, ddz = dz;
     const float ifx = (float)(1.0 / ddx), ify = (float)(1.0 / ddy), ifz = (float)(1.0 / ddz);     // for the per-run box test
+    // @phase step
     for (;;) {
         // ---- STEP: on to the next occupied voxel
         const long long t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        if (COUNT && __ballot(alive && !first)) wc.loops[RT_LOOP_ADVANCE] += 1;
         if (alive && !first) {
             alive = dda_advance(w, early && hit, st.t, slack);
             if (COUNT && alive) ++wc.steps;
@@ -1614,6 +1663,16 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // at most RT_STEPS_PER_ROUND empty voxels per round: a ray on a long empty stretch goes on in the next round
         // instead of keeping the others waiting (it takes part in this round with an empty voxel)
         int steps_left = RT_STEPS_PER_ROUND;
+        if (COUNT) {          // iterations the wavefront makes: those of the lane that steps the most
+            uint32_t it = 0;
+            Dda c = w;
+            bool a2 = alive;
+            int sl = RT_STEPS_PER_ROUND;
+            while (a2 && !((bitmap[c.cell >> 5] >> (c.cell & 31)) & 1u) && sl > 0) { a2 = dda_advance(c, early && hit, st.t, slack); --sl; ++it; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) it = max(it, (uint32_t)__shfl_xor((int)it, off));
+            wc.loops[RT_LOOP_STEP_ITER] += it;
+        }
         while (alive && !((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u) && steps_left > 0) {
             alive = dda_advance(w, early && hit, st.t, slack);
             if (COUNT && alive) ++wc.steps;
@@ -1629,6 +1688,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         if (COUNT) { wc.rounds += 1; wc.cyc_step += (uint32_t)(t1 - t0); if (alive) wc.tests += cend - cbeg; }
         // most rounds of a unit only move a few rays on through empty space: nothing to cull or to test
         if (!un) continue;
+        if (COUNT) wc.loops[RT_LOOP_ROUNDS_AT_VOXEL] += 1;
+        // @phase cull
         // ---- CULL (crowded voxels only): every ray against the boxes of the 64-record runs of ITS voxel, lane = ray.
         // A voxel's records are visited in runs of 64. Crowded voxels use runs aligned to multiples of 64 in the record
         // array, which is what the per-run boxes describe; a run is skipped for a ray when the ray's whole line misses
@@ -1664,6 +1725,15 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         };
         // (a) voxels with up to RT_CULL_LANE_RUNS runs: lane = ray, a short loop over the runs of its own voxel,
         //     all voxels of the round at once
+        if (COUNT) {
+            const bool ca = cull && nrun_me <= (cull_min >> 16);
+            if (__ballot(ca)) {
+                uint32_t mx = ca ? nrun_me : 0u, sm = mx;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); sm += (uint32_t)__shfl_xor((int)sm, off); }
+                wc.loops[RT_LOOP_CULL_A_ROUNDS] += 1; wc.loops[RT_LOOP_CULL_A_ITER] += mx; wc.loops[RT_LOOP_CULL_A_LANES] += sm;
+            }
+        }
         if (cull && nrun_me <= (cull_min >> 16)) {
             const float4* bb = s.blk_bounds + 3ull * (org >> 6);
             need0 = 0;
@@ -1682,6 +1752,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 const uint32_t vo = (uint32_t)__builtin_amdgcn_readlane((int)org, leader) >> 6;
                 const unsigned long long mem = __ballot(cull && cbeg == vb);
                 dn &= ~mem;
+                if (COUNT) { wc.loops[RT_LOOP_CULL_B_VOXELS] += 1; wc.loops[RT_LOOP_CULL_B_RAYS] += (uint32_t)__popcll(mem); }
                 float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, b0 = a0, b1 = a0, b2 = a0;
                 const bool h0 = (uint32_t)lane < vn, h1 = (uint32_t)lane + 64u < vn;
                 if (h0) { const float4* q = s.blk_bounds + 3ull * (vo + lane); a0 = q[0]; a1 = q[1]; a2 = q[2]; }
@@ -1704,6 +1775,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 if (lane == leader) { any0 = u0; any1 = u1; }      // runs some ray of this voxel needs, kept in its first lane
             }
         }
+        // @phase own
         // ---- OWN: voxels with a handful of records, lane = ray. In a sparse scene the rays of a unit stand in dozens of
         // different voxels of a few triangles each; streamed as (voxel, run) items every one of them would cost a trip of
         // the whole wavefront for a handful of busy lanes. Here the records of every such ray's voxel are tested by the
@@ -1793,6 +1865,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         }
         const long long t2 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (COUNT) wc.cyc_cull += (uint32_t)(t2 - t1);
+        // @phase itemgen
         // ---- TEST: the round's (voxel, needed run) items in order: voxels by their lowest lane, runs ascending. The
         // generator runs one item ahead of the tests so that the next run's records are in flight, also across voxels.
         uint32_t sb = 0, se = 0, sorg = 0, sk = 0, snrun = 0;
@@ -1800,7 +1873,9 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         bool scull = false;
         struct Item { uint32_t base, b, e; unsigned long long rays; };
         auto next_item = [&](Item& it) -> bool {
+            if (COUNT) wc.loops[RT_LOOP_ITEMGEN_CALLS] += 1;
             for (;;) {
+                if (COUNT) wc.loops[RT_LOOP_ITEMGEN_ITER] += 1;
                 if (sk >= snrun) {
                     if (!un) return false;
                     const int leader = __ffsll((long long)un) - 1;
@@ -1814,7 +1889,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     sk = 0;
                     sany0 = ~0ull; sany1 = ~0ull;
                     if (scull && snrun > (cull_min >> 16)) { sany0 = bcast_u64(any0, leader); sany1 = bcast_u64(any1, leader); }
-                    if (COUNT) wc.slots += 1;
+                    if (COUNT) { wc.slots += 1; wc.loops[RT_LOOP_ITEMGEN_VOXELS] += 1; }
                 }
                 // crowded voxels: straight to the next run that some ray needs
                 if (sk < 64u) {
@@ -1832,6 +1907,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 if (rays) { it.base = sorg + 64u * k; it.b = sb; it.e = se; it.rays = rays; return true; }
             }
         };
+        // @phase load
         auto load_item = [&](const Item& it, float4& r0, float4& r1, float4& r2) {
             const uint32_t p = it.base + lane;
             const uint32_t q = (p >= it.b && p < it.e) ? p : it.b;
@@ -1843,6 +1919,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // time of two items' tests to arrive (slots A and B take turns). Every load below is unconditional -- a slot
         // without a next item loads the item it has again -- because loads behind a branch make the compiler merge the
         // two slots into one and wait for all outstanding loads before each test.
+        // @phase item
         auto process = [&](const Item& cur, const TriRec& t) {
             const uint32_t base = cur.base, e = cur.e;
             const bool have = base + lane >= cur.b && base + lane < e;
@@ -1850,6 +1927,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             unsigned long long lm = cur.rays & __ballot(alive);          // rays that were hit meanwhile (shadow query) drop out
             if (COUNT) { wc.lanes += (uint32_t)__popcll(have_m) * (uint32_t)__popcll(lm); wc.items += 1; wc.trips += (uint32_t)__popcll(lm); }
             wc.fb_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc.fb_items + 1u));      // a scalar register, not one per lane
+            if (COUNT) { wc.loops[RT_LOOP_ITEMS] += 1; wc.loops[RT_LOOP_TRIPS] += (uint32_t)__popcll(lm); if (lm) wc.loops[RT_LOOP_ITEMS_WITH_RAYS] += 1; }
             if (lm) {
                 // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
                 double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
@@ -1864,6 +1942,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 // instead, and runs with few rays do not defer at all.
                 int dc = -1;
                 bool at_once = !DEFER || __popcll(lm) < RT_DEFER_MIN_RAYS;
+                // @phase trip
                 for (;;) {
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
@@ -1894,9 +1973,11 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     unsigned long long pm = 0;
                     double tt = 0.0;
                     if (cand) wc.fb_hits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc.fb_hits + 1u));
+                    if (COUNT && cand) wc.loops[RT_LOOP_TRIPS_CAND] += 1;
                     if (DEFER && !at_once && (cand & (cand - 1ull)) == 0ull) {
                         if (cand && lane == i) dc = __ffsll((long long)cand) - 1;
                     } else if (cand) {
+                        // @phase resolve
                         // The three quotients have one denominator: where the exponents of all operands allow it (see
                         // div_rcp) the reciprocal part of the division is evaluated once. Any candidate lane outside the
                         // window (zeros, infinities and NaNs included) sends the wavefront down the plain path.
@@ -1924,6 +2005,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                         }
                     }
                     if (RULE == 1 && ANY_HIT) pm &= __builtin_amdgcn_fcmp(tt, (double)eps, 2) & __builtin_amdgcn_fcmp(tt, (double)INFINITY, 4);
+                    if (COUNT && pm) { wc.loops[RT_LOOP_TRIPS_PASS] += 1; wc.loops[RT_LOOP_PASS_LANES] += (uint32_t)__popcll(pm); }
                     if (pm) {
                         if (ANY_HIT) {
                             if (lane == i) {
@@ -1947,6 +2029,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                         }
                     }
                 }
+                // @phase defer
                 if (!DEFER) break;
                 // the rays that noted a candidate
                 const unsigned long long dm = __ballot(dc >= 0);
@@ -2003,6 +2086,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 }
             }
         };
+        // @phase pipe
         Item itA, itB;
         float4 a0, a1, a2, b0, b1, b2;
         bool hA = next_item(itA);
@@ -2106,6 +2190,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 load_item(itC, c0, c1, c2);
             }
         }
+        // @phase apply
         if (!ANY_HIT && RULE == 0) vb_apply(vb, st);
         if (!ANY_HIT && RULE == 1 && pb_t < *td) {       // strict: an equal distance found in an earlier voxel stays
             *td = pb_t; st.id = pb_id; hit = true;
@@ -2116,9 +2201,24 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
     return hit;
 }
 
+// @phase other
 // pow() for exponents other than the reference's 4. Kept out of line: inlined, its two dozen polynomial constants are
 // hoisted into registers for the whole persistent loop of the trace kernel.
 __device__ __attribute__((noinline)) double pow_general(double x, double a) { return pow(x, a); }
+
+// Loop counts of the counting build's frames since the last read (RT_LOOP_*: primary walks first, then shadow walks).
+__device__ unsigned long long rt_loop_counts[2 * RT_LOOP_WORDS];
+hipError_t rt_read_loop_counts(unsigned long long* out, int n, int reset) {
+    unsigned long long host[2 * RT_LOOP_WORDS] = {};
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(rt_loop_counts), sizeof(host));
+    if (e != hipSuccess) return e;
+    for (int k = 0; k < n && k < 2 * RT_LOOP_WORDS; ++k) out[k] = host[k];
+    if (reset) {
+        unsigned long long zero[2 * RT_LOOP_WORDS] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(rt_loop_counts), zero, sizeof(zero));
+    }
+    return e;
+}
 
 struct RtTraceArgs {
     RtSceneDev s;
@@ -2231,6 +2331,7 @@ __device__ __forceinline__ uint32_t queue_part(uint32_t n, uint32_t q) {
     return (n * q) / RT_QUEUE_HEADS;                  // n < 2^21 tiles (RT_MAX_TILES), q <= 8
 }
 
+// @phase kernel_setup
 template <bool COUNT, bool OWN, int MODE = 0, int IDX = 2, bool DEFER = false>
 // Four blocks per CU (128 VGPRs, a few of them spilled) for the streamed path of crowded grids; three (144 VGPRs, nothing
 // spilled) for the variants that also hold the small-voxel loop, whose frames are bound by the longest chain of one wavefront
@@ -2267,6 +2368,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
     unsigned long long acc_fb = 0;        // record runs streamed (low half) and trips with a candidate triangle (high half)
     unsigned long long acc_ray[6] = {0, 0, 0, 0, 0, 0}, acc_w[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, max_cyc = 0, max_rounds = 0;
     const long long wave_t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    uint32_t acc_loops[2 * RT_LOOP_WORDS] = {};          // counting build: loop counts of the primary and of the shadow walks
     uint32_t slot_next = 0;
     // The queue has one head per XCD, each in a cache line of its own: atomics on one line are served one after the
     // other, about 7 ns each, and with a single head for the 4096 wavefronts of a launch that queue of atomics, not the
@@ -2278,6 +2380,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
     // The head a wavefront draws from lives in LDS, not in a register: the loop below has no scalar register to spare.
     __shared__ uint32_t wave_head[RT_WAVES_PER_BLOCK];
     if (!DEFER && lane == 0) wave_head[threadIdx.x >> 6] = ((uint32_t)__builtin_amdgcn_s_getreg(RT_GETREG_XCC_ID) & 7u) % RT_QUEUE_HEADS;
+    // @phase dequeue
     for (;;) {
         asm volatile("" ::: "memory");
         const RtSceneDev& s = A->s;
@@ -2341,6 +2444,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
             }
             uslot = (uint32_t)__builtin_amdgcn_readlane((int)(all_end - all_units), li) + (t0 << ushift) + rel;
         }
+        // @phase raygen
         // lane -> pixel of the tile: the tile's 64 pixels are numbered along a Z-order curve and unit `sub` owns
         // 64 >> ushift consecutive ones (a compact 8x8, 8x4, 4x4, 4x2 ... block); the other lanes carry no ray
         const int per_unit = 64 >> ushift;
@@ -2371,6 +2475,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
         const unsigned long long rt_start = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
         const bool hit_any = wave_walk<false, true, COUNT, OWN, 0, IDX, DEFER>(s, bitmap, lane, live, cam.pos[0], cam.pos[1], cam.pos[2], dx, dy, dz, 0.f, false,
                                                        sh.eps, f.walk_full == 0, f.early_slack, (uint32_t)f.cull_min, per_unit, st, wp);
+        // @phase shade
         float colr = 0.f, colg = 0.f, colb = 0.f;
         float poix = 0.f, poiy = 0.f, poiz = 0.f, sx = 0.f, sy = 0.f, sz = 1.f;
         // A triangle can pass the barycentric test with a hit distance that is NaN or +inf (overflowing coordinates): the
@@ -2428,6 +2533,8 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
                 acc_w[3] += wp.cyc_test + ws.cyc_test; acc_w[4] += cyc; acc_w[5] += 1;
                 acc_w[6] += (unsigned long long)wp.lanes + ws.lanes; acc_w[7] += wp.items + ws.items; acc_w[8] += wp.trips + ws.trips;
                 acc_w[9] += wp.cyc_cull + ws.cyc_cull;
+#pragma unroll
+                for (int k = 0; k < RT_LOOP_WORDS; ++k) { acc_loops[k] += wp.loops[k]; acc_loops[RT_LOOP_WORDS + k] += ws.loops[k]; }
                 if (cyc > max_cyc) max_cyc = cyc;
                 if (wp.rounds + ws.rounds > max_rounds) max_rounds = wp.rounds + ws.rounds;
                 if (lane == 0 && o.unit_cost) {
@@ -2449,6 +2556,7 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
             }
         }
         }
+        // @phase write
         if (in_unit) write_pixel(f, o, x, y_local, cr, cg, cb, id);
     }
     // end of the kernel = the latest exit of a wavefront (the clock only goes up, so the maximum also beats whatever an
@@ -2488,6 +2596,9 @@ __global__ void __launch_bounds__(RT_WAVES_PER_BLOCK * 64, OWN ? 3 : 4) k_trace(
                 atomicMax(&counters[21], acc_w[4]);                                           // busiest wavefront
                 atomicMin(&counters[22], (unsigned long long)wave_t0);                         // first start
                 atomicMax(&counters[23], (unsigned long long)__builtin_amdgcn_s_memtime());    // last end
+#pragma unroll
+                for (int k = 0; k < 2 * RT_LOOP_WORDS; ++k)
+                    if (acc_loops[k]) atomicAdd(&rt_loop_counts[k], (unsigned long long)acc_loops[k]);
             }
         }
     }
