@@ -142,7 +142,9 @@ int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_grid, void* d_
  * lists, triangle records in voxel order, run bounds, work lists, counters) is a fixed array of about 32 MB that every GPU
  * the library runs on holds until the process ends. It issues kernels and memsets on `stream` only (no events, no second
  * stream, no host synchronisation) and rebuilds the grid on every call. The scene's triangles must already be on the
- * device: call rt_scene_upload() once, outside the code that cannot allocate. Limits, rejected with RT_ERR_INVALID and a
+ * device: call rt_scene_upload() once, outside the code that cannot allocate and outside any stream capture;
+ * rt_scene_upload() also looks up the device address of the fixed array (a module load under a lock), so that this entry
+ * point only reads a stored pointer and its very first call on a device may already be under capture. Limits, rejected with RT_ERR_INVALID and a
  * message: 524,288 (voxel, triangle) references in the scene's grid; 32,640 tiles of 8x8 pixels in the output buffers
  * (1920 x 1088 pixels). All calls on one GPU share the one array, which keeps the last call's contents: calls that overlap
  * in time on one GPU (two streams, two threads) race; calls on one stream, or ordered by the caller, are safe, also for

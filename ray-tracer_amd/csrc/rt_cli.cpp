@@ -9,7 +9,10 @@
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 struct MeshArg { std::string path; int has_vt; float color[3]; float offset[3]; int scale; rt_material mat; bool has_mat; };
@@ -84,51 +87,126 @@ int main(int argc, char** argv) {
         }
         return sc;
     };
+    auto print_stats = [&](rt_scene* sc) {
+        rt_frame_stats st;
+        if (rt_scene_last_stats(sc, &st) == RT_OK)
+            fprintf(stderr, "triangles %llu grid %dx%dx%d refs %u build %.3f ms render %.3f ms hits %llu shadowed %llu\n",
+                    (unsigned long long)st.n_triangles, st.grid_n[0], st.grid_n[1], st.grid_n[2], st.n_refs, st.ms_build, st.ms_render,
+                    (unsigned long long)st.hits, (unsigned long long)st.shadowed);
+        else
+            fprintf(stderr, "rt: no stats: %s\n", rt_last_error());
+    };
     if (gpus > 0) {
         // The frame on several GPUs of this process: every GPU holds the scene and renders the bands of its part, one RCCL
-        // gather brings them to the first GPU, which puts them in frame order.
+        // gather brings them to the first GPU, which puts them in frame order. Every GPU has a host thread of its own that
+        // issues its frames (frame k on lane k % D of that GPU, D frames in flight), so the host cost of issuing a frame is
+        // paid side by side; the main thread posts the gather of frame k, on the lanes of frame k, once every GPU has
+        // issued that frame, and a GPU may run at most D frames ahead of the gathers (its band buffers are per lane).
         if (gpus > 64) { usage(); return 2; }
         auto fail = [&](const char* what) { fprintf(stderr, "rt: %s: %s\n", what, rt_last_error()); return 1; };
         rt_comm* comm = nullptr;
         if (rt_comm_create(gpus, nullptr, &comm)) return fail("rt_comm_create");
-        std::vector<rt_scene*> sc((size_t)gpus, nullptr);
-        std::vector<void*> d_part((size_t)gpus, nullptr);
+        struct Dev { rt_scene* sc = nullptr; void* lane[8] = {}; void* d_part[8] = {}; double enqueue_ms = 0; std::string err; };
+        std::vector<Dev> dev((size_t)gpus);
         p.part_count = gpus; p.part_index = 0;
         const size_t part_bytes = (size_t)rt_part_rows(&p) * p.width * 3, frame_bytes = (size_t)p.width * p.height * 3;
-        void *d_stacked = nullptr, *d_frame = nullptr;
+        int depth = frames > 0 ? (in_flight < 1 ? 1 : (in_flight > 8 ? 8 : in_flight)) : 1;
         for (int r = 0; r < gpus; ++r) {
             if (hipSetDevice(r) != hipSuccess) { fprintf(stderr, "rt: cannot select GPU %d\n", r); return 1; }
-            if (!(sc[r] = load_scene())) return 1;
-            if (rt_scene_upload(sc[r])) return fail("rt_scene_upload");
-            if (hipMalloc(&d_part[r], part_bytes) != hipSuccess) { fprintf(stderr, "rt: out of device memory\n"); return 1; }
+            if (!(dev[r].sc = load_scene())) return 1;
+            if (rt_scene_upload(dev[r].sc) || rt_scene_set_frames_in_flight(dev[r].sc, depth)) return fail("rt_scene_upload");
+            const int n = rt_streams_create(depth, dev[r].lane);
+            if (n < 1) return fail("rt_streams_create");
+            if (n < depth) {                       // fewer streams that run side by side than asked for: every GPU uses that many
+                for (int q = 0; q <= r; ++q) { (void)hipSetDevice(q); (void)rt_scene_set_frames_in_flight(dev[q].sc, n); }
+                depth = n;
+            }
+        }
+        void *d_stacked[8] = {}, *d_frame[8] = {};
+        for (int r = 0; r < gpus; ++r) {
+            (void)hipSetDevice(r);
+            for (int k = 0; k < depth; ++k)
+                if (hipMalloc(&dev[r].d_part[k], part_bytes) != hipSuccess) { fprintf(stderr, "rt: out of device memory\n"); return 1; }
         }
         (void)hipSetDevice(0);
-        if (hipMalloc(&d_stacked, part_bytes * gpus) != hipSuccess || hipMalloc(&d_frame, frame_bytes) != hipSuccess) { fprintf(stderr, "rt: out of device memory\n"); return 1; }
+        for (int k = 0; k < depth; ++k)
+            if (hipMalloc(&d_stacked[k], part_bytes * gpus) != hipSuccess || hipMalloc(&d_frame[k], frame_bytes) != hipSuccess) { fprintf(stderr, "rt: out of device memory\n"); return 1; }
         const int count = frames > 0 ? frames : 1;
         double ms = 0;
         for (int pass = 0; pass < (frames > 0 ? 2 : 1); ++pass) {        // with --frames the first pass warms up
-            const int n_pass = (frames > 0 && pass == 0) ? 3 : count;
+            const int n_pass = (frames > 0 && pass == 0) ? 2 * depth : count;
+            std::mutex mu;
+            std::condition_variable cv;
+            std::vector<int> issued((size_t)gpus, 0);
+            int gathered = 0;
+            bool stop = false;
             const auto t0 = std::chrono::steady_clock::now();
-            for (int k = 0; k < n_pass; ++k) {
-                for (int r = 0; r < gpus; ++r) {
-                    (void)hipSetDevice(r);
+            std::vector<std::thread> th;
+            for (int r = 0; r < gpus; ++r) {
+                th.emplace_back([&, r] {
+                    Dev& d = dev[r];
+                    d.enqueue_ms = 0;
+                    if (hipSetDevice(r) != hipSuccess) d.err = "cannot select the GPU";
                     rt_params q = p;
                     q.part_index = r;
-                    if (rt_render_device(sc[r], &q, 1, nullptr, d_part[r], nullptr, nullptr)) return fail("rt_render_device");
-                }
-                if (rt_gather_bands(comm, &p, d_part.data(), d_stacked, d_frame, 3, nullptr)) return fail("rt_gather_bands");
+                    for (int k = 0; k < n_pass && d.err.empty(); ++k) {
+                        {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&] { return stop || k < gathered + depth; });
+                            if (stop) break;
+                        }
+                        const auto e0 = std::chrono::steady_clock::now();
+                        if (rt_render_device(d.sc, &q, 1, nullptr, d.d_part[k % depth], nullptr, d.lane[k % depth])) d.err = rt_last_error();
+                        d.enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e0).count();
+                        {
+                            std::lock_guard<std::mutex> lk(mu);
+                            issued[r] = k + 1;
+                            if (!d.err.empty()) stop = true;
+                        }
+                        cv.notify_all();
+                    }
+                    if (!d.err.empty()) { std::lock_guard<std::mutex> lk(mu); stop = true; cv.notify_all(); }
+                });
             }
+            int rc = 0;
+            for (int k = 0; k < n_pass && !rc; ++k) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { if (stop) return true; for (int v : issued) if (v < k + 1) return false; return true; });
+                    if (stop) break;
+                }
+                void* parts[64]; void* lanes[64];
+                for (int r = 0; r < gpus; ++r) { parts[r] = dev[r].d_part[k % depth]; lanes[r] = dev[r].lane[k % depth]; }
+                if (rt_gather_bands(comm, &p, parts, d_stacked[k % depth], d_frame[k % depth], 3, lanes)) rc = fail("rt_gather_bands");
+                { std::lock_guard<std::mutex> lk(mu); gathered = k + 1; if (rc) stop = true; }
+                cv.notify_all();
+            }
+            for (auto& t : th) t.join();
+            for (int r = 0; r < gpus; ++r)
+                if (!dev[r].err.empty()) { fprintf(stderr, "rt: GPU %d: %s\n", r, dev[r].err.c_str()); rc = 1; }
+            if (rc) return 1;
             for (int r = 0; r < gpus; ++r) { (void)hipSetDevice(r); if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "rt: device error\n"); return 1; } }
             ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n_pass;
         }
-        if (frames > 0) fprintf(stderr, "%d frames of %dx%d on %d GPUs: %.4f ms per frame\n", frames, p.width, p.height, gpus, ms);
+        if (frames > 0) {
+            double enq = 0;
+            for (int r = 0; r < gpus; ++r) enq += dev[r].enqueue_ms / count;
+            fprintf(stderr, "%d frames of %dx%d on %d GPUs, %d in flight: %.4f ms per frame; host enqueue %.4f ms per frame and GPU (one host thread per GPU)\n",
+                    frames, p.width, p.height, gpus, depth, ms, enq / gpus);
+        }
         (void)hipSetDevice(0);
         std::vector<unsigned char> img(frame_bytes);
-        if (hipMemcpy(img.data(), d_frame, frame_bytes, hipMemcpyDeviceToHost) != hipSuccess || rt_write_ppm_u8(out.c_str(), img.data(), p.width, p.height)) {
+        if (hipMemcpy(img.data(), d_frame[(count - 1) % depth], frame_bytes, hipMemcpyDeviceToHost) != hipSuccess || rt_write_ppm_u8(out.c_str(), img.data(), p.width, p.height)) {
             fprintf(stderr, "rt: cannot write %s\n", out.c_str()); return 1;
         }
-        (void)hipFree(d_stacked); (void)hipFree(d_frame);
-        for (int r = 0; r < gpus; ++r) { (void)hipSetDevice(r); (void)hipFree(d_part[r]); rt_scene_destroy(sc[r]); }
+        if (stats) print_stats(dev[0].sc);
+        for (int k = 0; k < depth; ++k) { (void)hipFree(d_stacked[k]); (void)hipFree(d_frame[k]); }
+        for (int r = 0; r < gpus; ++r) {
+            (void)hipSetDevice(r);
+            for (int k = 0; k < depth; ++k) (void)hipFree(dev[r].d_part[k]);
+            rt_scene_destroy(dev[r].sc);             // before its streams go: a scene keeps the streams of its last frames
+            (void)rt_streams_destroy(depth, dev[r].lane);
+        }
         rt_comm_destroy(comm);
         return 0;
     }
@@ -159,18 +237,15 @@ int main(int argc, char** argv) {
             fprintf(stderr, "rt: cannot write %s\n", out.c_str()); return 1;
         }
         for (int k = 0; k < n; ++k) (void)hipFree(d_u8[k]);
+        // the scene still refers to the lanes of its last frames: stats first, then the scene, then the streams
+        if (stats) print_stats(s);
+        rt_scene_destroy(s);
         (void)rt_streams_destroy(n, lane);
-    } else {
-        int rc = rt_render_ppm(s, &p, out.c_str());
-        if (rc) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
+        return 0;
     }
-    if (stats) {
-        rt_frame_stats st;
-        if (rt_scene_last_stats(s, &st) == RT_OK)
-            fprintf(stderr, "triangles %llu grid %dx%dx%d refs %u build %.3f ms render %.3f ms hits %llu shadowed %llu\n",
-                    (unsigned long long)st.n_triangles, st.grid_n[0], st.grid_n[1], st.grid_n[2], st.n_refs, st.ms_build, st.ms_render,
-                    (unsigned long long)st.hits, (unsigned long long)st.shadowed);
-    }
+    int rc = rt_render_ppm(s, &p, out.c_str());
+    if (rc) { fprintf(stderr, "rt: %s\n", rt_last_error()); return 1; }
+    if (stats) print_stats(s);
     rt_scene_destroy(s);
     return 0;
 }

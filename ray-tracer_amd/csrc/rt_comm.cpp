@@ -19,6 +19,7 @@ struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;          // optional
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -38,6 +39,7 @@ Rccl& rccl() {
         if (!r.handle) return;
         r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.handle, "ncclCommInitAll");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))dlsym(r.handle, "ncclCommAbort");
         r.GroupStart = (decltype(r.GroupStart))dlsym(r.handle, "ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.handle, "ncclGroupEnd");
         r.Gather = (decltype(r.Gather))dlsym(r.handle, "ncclGather");
@@ -51,6 +53,7 @@ Rccl& rccl() {
 struct rt_comm {
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
+    bool broken = false;          // a gather failed after some ranks had posted theirs: the communicators were aborted
 };
 
 #define RCCL_TRY(expr)                                                                                              \
@@ -96,7 +99,7 @@ extern "C" int rt_comm_create(int32_t n_devices, const int32_t* devices, rt_comm
 
 extern "C" void rt_comm_destroy(rt_comm* c) {
     if (!c) return;
-    if (rccl().ok)
+    if (rccl().ok && !c->broken)
         for (ncclComm_t k : c->comms)
             if (k) (void)rccl().CommDestroy(k);
     delete c;
@@ -111,23 +114,50 @@ extern "C" int rt_gather_bands(rt_comm* c, const rt_params* p, void* const* d_pa
     if (p->part_count != n) return rt_set_error(RT_ERR_INVALID, "rt_gather_bands: part_count %d but the communicator has %d devices", p->part_count, n);
     const size_t part_bytes = (size_t)rt_part_rows(p) * (size_t)p->width * (size_t)elem_bytes;
     if (part_bytes == 0) return rt_set_error(RT_ERR_INVALID, "rt_gather_bands: empty frame");
+    if (c->broken) return rt_set_error(RT_ERR_HIP, "rt_gather_bands: the communicator is unusable after a failed gather");
+    // Everything that can be checked is checked BEFORE the group is opened: a gather that is posted on some ranks of the
+    // communicator and not on the others leaves the posted ranks' kernels waiting on their streams for ever.
+    for (int r = 0; r < n; ++r)
+        if (!d_parts[r]) return rt_set_error(RT_ERR_INVALID, "rt_gather_bands: d_parts[%d] is NULL", r);
     int current = 0;
     HIP_TRY_C(hipGetDevice(&current));
-    // one gather, every device's call inside one group: each peer writes its bands over its own xGMI link into the root
-    RCCL_TRY(rccl().GroupStart());
-    ncclResult_t first_err = ncclSuccess;
     for (int r = 0; r < n; ++r) {
-        if (!d_parts[r]) { first_err = ncclInvalidArgument; break; }
+        const hipError_t e = hipSetDevice(c->devices[r]);
+        if (e != hipSuccess) {
+            (void)hipSetDevice(current);
+            return rt_set_error(RT_ERR_HIP, "rt_gather_bands: cannot select device %d: %s", c->devices[r], hipGetErrorString(e));
+        }
+    }
+    // one gather, every device's call inside one group: each peer writes its bands over its own xGMI link into the root
+    {
+        const ncclResult_t gs = rccl().GroupStart();
+        if (gs != ncclSuccess) { (void)hipSetDevice(current); return rt_set_error(RT_ERR_HIP, "ncclGroupStart failed: %s", rccl().GetErrorString(gs)); }
+    }
+    ncclResult_t first_err = ncclSuccess;
+    int posted = 0;
+    for (int r = 0; r < n; ++r) {
         if (hipSetDevice(c->devices[r]) != hipSuccess) { first_err = ncclUnhandledCudaError; break; }
         const ncclResult_t e = rccl().Gather(d_parts[r], r == 0 ? d_stacked : nullptr, part_bytes, ncclUint8, 0, c->comms[r],
                                              (hipStream_t)(streams ? streams[r] : nullptr));
         if (e != ncclSuccess) { first_err = e; break; }
+        ++posted;
+    }
+    if (first_err != ncclSuccess) {
+        // Some ranks are posted, the rest are not: nothing may be left waiting for them. The group is closed (it has to be,
+        // for the thread's sake), then the communicators are aborted, which releases the kernels of the ranks that were
+        // posted, and the rt_comm refuses further use.
+        c->broken = true;
+        (void)rccl().GroupEnd();
+        if (rccl().CommAbort)
+            for (ncclComm_t k : c->comms)
+                if (k) (void)rccl().CommAbort(k);
+        (void)hipSetDevice(current);
+        return rt_set_error(RT_ERR_HIP, "ncclGather failed on rank %d of %d (%s); the communicator has been aborted", posted, n, rccl().GetErrorString(first_err));
     }
     const ncclResult_t ge = rccl().GroupEnd();
     (void)hipSetDevice(c->devices[0]);
     int rc = RT_OK;
-    if (first_err != ncclSuccess) rc = rt_set_error(RT_ERR_HIP, "ncclGather failed: %s", rccl().GetErrorString(first_err));
-    else if (ge != ncclSuccess) rc = rt_set_error(RT_ERR_HIP, "ncclGroupEnd failed: %s", rccl().GetErrorString(ge));
+    if (ge != ncclSuccess) { c->broken = true; rc = rt_set_error(RT_ERR_HIP, "ncclGroupEnd failed: %s", rccl().GetErrorString(ge)); }
     // frame order on the root, on the root's stream (behind its part of the gather)
     if (rc == RT_OK) rc = rt_deinterleave_device(p, d_stacked, d_frame, elem_bytes, streams ? streams[0] : nullptr);
     (void)hipSetDevice(current);

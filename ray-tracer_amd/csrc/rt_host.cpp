@@ -14,6 +14,7 @@
 #include <functional>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -154,6 +155,7 @@ struct rt_scene {
     int indexed_override = -1;               // RT_INDEXED_RECS: 0 / 1, -1 = the library decides
     int defer_override = -1;                 // RT_DEFER: 0 / 1, -1 = by the counts of earlier frames
     unsigned long long* feedback = nullptr;  // one word of pinned host memory the frames' kernels report to (RtBuildDev::feedback)
+    void* noalloc_base = nullptr;            // this device's copy of the fixed working memory of rt_render_device_noalloc (looked up at upload)
     rt_params last_params;
     // experiment overrides, read once when the scene is created: RT_OWN_PATH (-1 = the library decides), RT_CULL_MIN
     // (1..65535), RT_CULL_LANE_RUNS (0..64), RT_BLOCKS_PER_CU (0 = no cap)
@@ -333,6 +335,24 @@ static void parse_obj_part(char* p, char* const end, const double off[3], double
     } catch (...) { out.failed = true; }
 }
 
+// fn(0) .. fn(n-1), each on a thread of its own. A thread that cannot be started (std::system_error: thread limit) does
+// not end the process: the parts without a thread run on the calling thread, and every thread that was started is joined
+// before anything leaves this function, also when fn throws here.
+template <class F>
+static void run_parts(int n, F fn) {
+    struct Joiner {
+        std::vector<std::thread> th;
+        ~Joiner() { for (std::thread& t : th) if (t.joinable()) t.join(); }
+    } workers;
+    workers.th.reserve((size_t)n);
+    int started = 0;
+    try {
+        for (; started < n; ++started) workers.th.emplace_back(fn, started);
+    } catch (const std::system_error&) {
+    }
+    for (int k = started; k < n; ++k) fn(k);
+}
+
 static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, const rt_material* mat, const float offset[3], int32_t scale_i) {
     (void)format_has_vt;   // the texture index is parsed by the reference but never used by the path
     if (!s || !path || !mat || !offset) return set_err(RT_ERR_INVALID, "rt_scene_add_obj: bad argument");
@@ -374,10 +394,7 @@ static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, co
         parts[0].verts.reserve(1 << 16);
         parse_obj_part(buf.data(), buf.data() + got, off, scale, parts[0]);
     } else {
-        std::vector<std::thread> workers;
-        for (int k = 0; k < n_parts; ++k)
-            workers.emplace_back(parse_obj_part, buf.data() + cut[k], buf.data() + cut[k + 1], off, scale, std::ref(parts[k]));
-        for (std::thread& t : workers) t.join();
+        run_parts(n_parts, [&](int k) { parse_obj_part(buf.data() + cut[k], buf.data() + cut[k + 1], off, scale, parts[k]); });
     }
     for (const ObjPart& pt : parts)
         if (pt.failed) throw std::bad_alloc();
@@ -415,11 +432,7 @@ static int64_t add_obj_impl(rt_scene* s, const char* path, int format_has_vt, co
         }
     };
     if (n_parts == 1) emit_part(0);
-    else {
-        std::vector<std::thread> workers;
-        for (int k = 0; k < n_parts; ++k) workers.emplace_back(emit_part, k);
-        for (std::thread& t : workers) t.join();
-    }
+    else run_parts(n_parts, emit_part);
     push_mesh(s, *mat);
     scene_touch(s);
     return (int64_t)n_new;
@@ -531,6 +544,8 @@ struct FrameMem {
     uint32_t *tile_list = nullptr, *tile_cost = nullptr, *queue_lists = nullptr;
     size_t tile_cap = 0;                     // tiles the three lists above can hold (queue_lists: RT_QUEUE_LISTS times as many)
     uint32_t* unit_cost = nullptr;           // counting frames only: 112 words per tile
+    bool report = true;                      // the frame's counters feed the scene's choice of kernel variant (not when the memory is
+                                             // shared with other scenes: the counters there may be another scene's)
 };
 
 static FrameMem scene_mem(const rt_scene* s, const WorkSet& w, bool indexed = false) {
@@ -581,7 +596,7 @@ static RtBuildDev build_args(rt_scene* s, const FrameMem& m) {
     b.stamp = nullptr;
     b.sorted = m.sorted ? 1 : 0;
     b.indexed = m.indexed ? 1 : 0;
-    b.feedback = s->feedback;
+    b.feedback = m.report ? s->feedback : nullptr;
     return b;
 }
 
@@ -764,6 +779,9 @@ extern "C" int rt_scene_upload(rt_scene* s) {
         HIP_TRY(hipHostMalloc((void**)&s->feedback, sizeof(unsigned long long), hipHostMallocDefault));
         *s->feedback = 0ull;
     }
+    // The fixed working memory of rt_render_device_noalloc: its address on this device is looked up here (module load, a
+    // lock), so that the entry point itself only reads a pointer and may be called under stream capture right after upload.
+    if (!s->noalloc_base) HIP_TRY(rt_noalloc_scratch(&s->noalloc_base));
     if (!s->stamps.p) {
         if ((rc = s->stamps.ensure(RT_STATS_RING * 4))) return rc;
         HIP_TRY(hipMemset(s->stamps.p, 0, RT_STATS_RING * 4 * sizeof(unsigned long long)));
@@ -990,7 +1008,7 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
     }
     const bool counting = s->count_work && m.unit_cost;
     // frames with a grid build: the build has cleared the counters (k_scan_sums)
-    if (build == 0) HIP_TRY(rt_launch_counters_reset(m.counters, s->feedback, side));
+    if (build == 0) HIP_TRY(rt_launch_counters_reset(m.counters, m.report ? s->feedback : nullptr, side));
     if (counting) HIP_TRY(hipMemsetAsync(m.counters + 22, 0xff, sizeof(unsigned long long), side));   // slot of a minimum
     {
         // background everywhere first: black, no hit
@@ -1155,9 +1173,8 @@ extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d
     if (tiles > RT_NOALLOC_MAX_TILES)
         return set_err(RT_ERR_INVALID, "rt_render_device_noalloc: a frame of %d x %d pixels has %zu tiles of 8x8, the fixed working memory holds %u",
                        p->width, rt_part_rows(p), tiles, (unsigned)RT_NOALLOC_MAX_TILES);
-    void* base_v = nullptr;
-    HIP_TRY(rt_noalloc_scratch(&base_v));
-    unsigned char* base = (unsigned char*)base_v;
+    if (!s->noalloc_base) return set_err(RT_ERR_INVALID, "rt_render_device_noalloc: call rt_scene_upload() first (this entry point allocates nothing)");
+    unsigned char* base = (unsigned char*)s->noalloc_base;
     constexpr RtNoallocLayout L = rt_noalloc_layout();
     FrameMem m;
     m.grid = (RtGrid*)(base + L.grid); m.bounds_enc = (uint32_t*)(base + L.bounds_enc);
@@ -1170,6 +1187,7 @@ extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d
     m.tile_list = (uint32_t*)(base + L.tile_list); m.tile_cost = (uint32_t*)(base + L.tile_cost); m.queue_lists = (uint32_t*)(base + L.queue_lists);
     m.tile_cap = RT_NOALLOC_MAX_TILES;
     m.unit_cost = nullptr;
+    m.report = false;
     // one stream, no events, no side stream: kernels and memsets only
     return render_frame(s, p, m, 2, nullptr, d_rgb_f32, d_rgb_u8, d_hit_id, (hipStream_t)stream, nullptr, nullptr);
 }

@@ -312,8 +312,8 @@ __global__ void k_scan_sums(RtBuildDev b) {
     // location in pinned host memory the host looks at, without waiting, when it picks the next frame's kernel variant).
     if (b.counters && blockIdx.x == 0) {
         if (threadIdx.x == 0 && b.feedback) {
-            const unsigned long long w = b.counters[RT_COUNTER_FEEDBACK];
-            if (w) __atomic_store_n(b.feedback, w, __ATOMIC_RELAXED);
+            // written whatever its value: a scene whose frames stop finding triangles leaves the deferred variant again
+            __atomic_store_n(b.feedback, b.counters[RT_COUNTER_FEEDBACK], __ATOMIC_RELAXED);
         }
         __syncthreads();
         if (threadIdx.x < RT_COUNTER_WORDS) b.counters[threadIdx.x] = 0ull;
@@ -869,8 +869,7 @@ __global__ void __launch_bounds__(256) k_run_area(RtBuildDev b, double* out) {
 // in has gone to the host (frames with a build do both in k_scan_sums).
 __global__ void k_counters_reset(unsigned long long* counters, unsigned long long* feedback) {
     if (threadIdx.x == 0 && feedback) {
-        const unsigned long long w = counters[RT_COUNTER_FEEDBACK];
-        if (w) __atomic_store_n(feedback, w, __ATOMIC_RELAXED);
+        __atomic_store_n(feedback, counters[RT_COUNTER_FEEDBACK], __ATOMIC_RELAXED);
     }
     __syncthreads();
     if (threadIdx.x < RT_COUNTER_WORDS) counters[threadIdx.x] = 0ull;

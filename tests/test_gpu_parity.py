@@ -578,6 +578,10 @@ def test_command_line_program_renders_a_stream_of_frames(tmp_path):
     r = subprocess.run([exe, "--frames", "11", "--in-flight", "3"], cwd=tmp_path, check=True, timeout=100, capture_output=True, text=True)
     assert "3 in flight" in r.stderr and "ms per frame" in r.stderr
     assert hashlib.md5((tmp_path / "test.ppm").read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
+    # --stats after a stream of frames: the stats are read while the frames' streams still exist
+    r = subprocess.run([exe, "--frames", "8", "--stats"], cwd=tmp_path, check=True, timeout=100, capture_output=True, text=True)
+    line = [l for l in r.stderr.splitlines() if l.startswith("triangles ")]
+    assert line and "triangles 20064 " in line[0] and "hits 32567 " in line[0] and "shadowed 14558" in line[0], r.stderr
 
 
 def test_command_line_program_through_the_multi_gpu_path(tmp_path):
@@ -591,6 +595,14 @@ def test_command_line_program_through_the_multi_gpu_path(tmp_path):
     r = subprocess.run([exe, "--gpus", "1", "--frames", "5"], cwd=tmp_path, timeout=100, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "on 1 GPUs" in r.stderr
+    assert hashlib.md5((tmp_path / "test.ppm").read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
+    # every GPU has a host thread that issues its frames, several in flight; the host cost of issuing a frame is reported
+    import re
+    r = subprocess.run([exe, "--gpus", "1", "--frames", "9", "--in-flight", "3", "--stats"], cwd=tmp_path, timeout=100, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"on 1 GPUs, (\d) in flight: ([0-9.]+) ms per frame; host enqueue ([0-9.]+) ms per frame and GPU", r.stderr)
+    assert m and int(m.group(1)) >= 1 and float(m.group(2)) > 0 and 0 < float(m.group(3)) < float(m.group(2)) * 4, r.stderr
+    assert "hits 32567 " in r.stderr
     assert hashlib.md5((tmp_path / "test.ppm").read_bytes()).hexdigest() == REFERENCE_TEST_PPM_MD5
 
 

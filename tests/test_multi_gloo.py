@@ -75,3 +75,45 @@ def test_row_map_matches_part_rows(rt):
                 assert len(m) == rt.part_rows(p)
                 seen += [int(y) for y in m if y >= 0]
             assert sorted(seen) == list(range(H))      # every frame row belongs to exactly one part
+
+
+def test_bench_gpus_n_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: main() must start the N ranks as a child process under
+    torch.distributed.run (never replace itself), pass its own arguments on and exit with the child's code, before torch or
+    the GPU is touched."""
+    import subprocess
+    for p in (ROOT,):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    cmd = bench.launch_command(2, ["--gpus", "2", "--steps", "5"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5"]
+    seen = {}
+
+    def fake_run(c, env=None, **kw):
+        seen["cmd"], seen["env"] = c, env
+        return subprocess.CompletedProcess(c, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setattr(os, "execv", lambda *a: (_ for _ in ()).throw(AssertionError("exec is not allowed")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    assert seen["cmd"][seen["cmd"].index("--nproc-per-node") + 1] == "4"
+    assert seen["cmd"][-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher (WORLD_SIZE set) nothing is started: main() goes on to its own rank's work
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    seen.clear()
+    # (stopped at its first GPU call, so that no process group is waited for on a box that has a GPU)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a: (_ for _ in ()).throw(RuntimeError("reached the rank's own work")))
+    try:
+        bench.main()
+    except BaseException:
+        pass
+    assert "cmd" not in seen

@@ -68,8 +68,7 @@ def test_noalloc_entry_point_under_graph_capture(rt):
     st = torch.cuda.Stream()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(st):
-        s.render_device_noalloc(p, d_rgb=rgb.data_ptr(), d_u8=u8.data_ptr(), d_ids=ids.data_ptr(), stream=st.cuda_stream)   # first call outside the capture
-        st.synchronize()
+        # the scene's first call of the entry point is the captured one: rt_scene_upload() has looked the array's address up
         g.capture_begin()
         s.render_device_noalloc(p, d_rgb=rgb.data_ptr(), d_u8=u8.data_ptr(), d_ids=ids.data_ptr(), stream=st.cuda_stream)
         g.capture_end()
