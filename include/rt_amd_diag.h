@@ -51,11 +51,12 @@ int rt_scene_last_counts(rt_scene* s, rt_frame_counts* out);
 int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n);
 
 /* Loop counts of the counting frames rendered on the current device since the last reset: how often the wavefronts of the
- * trace kernel went through each loop of the walk, 18 numbers for the primary walks, then the same 18 for the shadow walks,
+ * trace kernel went through each loop of the walk, 19 numbers for the primary walks, then the same 19 for the shadow walks,
  * in this order: rounds with a ray at an occupied voxel, rounds whose first voxel step ran, iterations of the empty-voxel
  * loop, rounds with lane = ray run culling, its iterations, the (ray, run) box tests in them, voxels culled lane = run,
  * rays broadcast there, item generator calls, its loop iterations, voxels it opened, items tested, items with a live ray,
- * (run, ray) trips, trips with a candidate triangle, trips with a passing triangle, passing triangles applied, walks.
+ * (run, ray) trips, trips with a candidate triangle, trips with a passing triangle, passing triangles applied, walks, trips left
+ * after the single-precision pre-filter.
  * Multiplied with the instructions of each loop body (tools/isa_attrib.py) they say where the kernel's instructions go.
  * Synchronises the device. No counterpart in the reference. */
 int rt_loop_counts(uint64_t* out, int32_t n, int32_t reset);

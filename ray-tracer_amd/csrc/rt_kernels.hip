@@ -999,6 +999,7 @@ enum {
     RT_LOOP_TRIPS_PASS,       // trips with a passing triangle
     RT_LOOP_PASS_LANES,       // passing triangles applied to a ray's summary
     RT_LOOP_WALKS,            // calls of wave_walk with a live ray
+    RT_LOOP_FILTER_KEPT,      // trips left after the single-precision pre-filter (exact trips run)
     RT_LOOP_WORDS
 };
 struct WalkCount {           // work counters of one ray (only maintained by the counting build of the kernel)
@@ -1551,6 +1552,8 @@ struct TriRec {
     double e1x, e1y, e1z;    // v0 - v1 (float subtraction, widened)
     double e2x, e2y, e2z;    // v0 - v2
     double m12;              // e1.y*e2.z - e2.y*e1.z
+    float f1x, f1y, f1z;     // v0 - v1 and v0 - v2 as stored (floats), for the single-precision pre-filter
+    float f2x, f2y, f2z;
 };
 
 __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, const float4 r2) {
@@ -1558,14 +1561,63 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
     t.v0x = r0.x; t.v0y = r0.y; t.v0z = r0.z; t.id = __float_as_uint(r0.w);
     t.e1x = r1.x; t.e1y = r1.y; t.e1z = r1.z;
     t.e2x = r2.x; t.e2y = r2.y; t.e2z = r2.z;
+    t.f1x = r1.x; t.f1y = r1.y; t.f1z = r1.z;
+    t.f2x = r2.x; t.f2y = r2.y; t.f2z = r2.z;
     t.m12 = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(r2.w) << 32) | __float_as_uint(r1.w)));
     return t;
+}
+
+// @phase filter
+// Single-precision pre-filter of the (run, ray) trips of rays with a common origin o, two rays per instruction.
+// With s = v0 - o, e1 = v0 - v1, e2 = v0 - v2 (the floats Triangle::Intersect works on) its determinants are dot products
+// of the ray direction d with vectors that do not depend on the ray:
+//     bnum = det[s e2 d] = d.(s x e2),   gnum = det[e1 s d] = d.(e1 x s),   A = det[e1 e2 d] = d.(e1 x e2),
+// and a triangle passes (beta > 0, gamma > 0, beta + gamma < 1) only if bnum, gnum and cnum = A - bnum - gnum all have the
+// sign of A. The three normals are made once per triangle and run; every ray then costs three dot products in float, and
+// a triangle is dropped for a ray only when two of the three numbers have DEFINITELY opposite signs: one above +E, one
+// below -E, with E a bound of everything single precision can have lost,
+//     |float result - exact determinant of the float inputs| <= 8 u (|e1|1 |e2|1 + |s|1 (|e1|1 + |e2|1)),   u = 2^-24, |d_i| <= 1
+// (two roundings per cross product component, two for the difference of the three normals, three per dot product; the
+// double-precision test of the reference differs from the exact determinants by 2^-29 of that). E is taken at 12 u times
+// the sum, plus 1e-30 for products that underflow; sums that overflow make E infinite and a NaN never compares as above
+// or below, so nothing is dropped then. A ray keeps its exact trip (the double-precision test below, unchanged) whenever
+// any triangle of the run survives, so results are those of the exact test alone.
+typedef float rt_f2 __attribute__((ext_vector_type(2)));
+struct PreFilter {
+    float nbx, nby, nbz, ngx, ngy, ngz, ncx, ncy, ncz, E;
+};
+__device__ __forceinline__ PreFilter prefilter_setup(const TriRec& t, float ox, float oy, float oz) {
+    PreFilter f;
+    const float sx = t.v0x - ox, sy = t.v0y - oy, sz = t.v0z - oz;
+    f.nbx = __builtin_fmaf(sy, t.f2z, -(sz * t.f2y)); f.nby = __builtin_fmaf(sz, t.f2x, -(sx * t.f2z)); f.nbz = __builtin_fmaf(sx, t.f2y, -(sy * t.f2x));
+    f.ngx = __builtin_fmaf(t.f1y, sz, -(t.f1z * sy)); f.ngy = __builtin_fmaf(t.f1z, sx, -(t.f1x * sz)); f.ngz = __builtin_fmaf(t.f1x, sy, -(t.f1y * sx));
+    const float nax = __builtin_fmaf(t.f1y, t.f2z, -(t.f1z * t.f2y)), nay = __builtin_fmaf(t.f1z, t.f2x, -(t.f1x * t.f2z)),
+                naz = __builtin_fmaf(t.f1x, t.f2y, -(t.f1y * t.f2x));
+    f.ncx = (nax - f.nbx) - f.ngx; f.ncy = (nay - f.nby) - f.ngy; f.ncz = (naz - f.nbz) - f.ngz;
+    const float ls = fabsf(sx) + fabsf(sy) + fabsf(sz), l1 = fabsf(t.f1x) + fabsf(t.f1y) + fabsf(t.f1z), l2 = fabsf(t.f2x) + fabsf(t.f2y) + fabsf(t.f2z);
+    f.E = (l1 * l2 + ls * (l1 + l2)) * 7.2e-7f + 1e-30f;
+    return f;
+}
+// Lanes (triangles) that rays i and j cannot be shown to miss. dxi.. are the two rays' directions.
+__device__ __forceinline__ void prefilter_pair(const PreFilter& f, rt_f2 rx, rt_f2 ry, rt_f2 rz, unsigned long long& keep_i, unsigned long long& keep_j) {
+    const rt_f2 b = __builtin_elementwise_fma((rt_f2){f.nbz, f.nbz}, rz, __builtin_elementwise_fma((rt_f2){f.nby, f.nby}, ry, (rt_f2){f.nbx, f.nbx} * rx));
+    const rt_f2 g = __builtin_elementwise_fma((rt_f2){f.ngz, f.ngz}, rz, __builtin_elementwise_fma((rt_f2){f.ngy, f.ngy}, ry, (rt_f2){f.ngx, f.ngx} * rx));
+    const rt_f2 c = __builtin_elementwise_fma((rt_f2){f.ncz, f.ncz}, rz, __builtin_elementwise_fma((rt_f2){f.ncy, f.ncy}, ry, (rt_f2){f.ncx, f.ncx} * rx));
+    // the largest of the three above +E and the smallest below -E: min(max3, -min3) > E (ordered compare: a NaN keeps the lane)
+    const float mi = __builtin_fminf(__builtin_fmaxf(__builtin_fmaxf(b.x, g.x), c.x), -__builtin_fminf(__builtin_fminf(b.x, g.x), c.x));
+    const float mj = __builtin_fminf(__builtin_fmaxf(__builtin_fmaxf(b.y, g.y), c.y), -__builtin_fminf(__builtin_fminf(b.y, g.y), c.y));
+    keep_i = ~__builtin_amdgcn_fcmpf(mi, f.E, 2);
+    keep_j = ~__builtin_amdgcn_fcmpf(mj, f.E, 2);
 }
 
 // @phase other
 // kernel variant DEFER: runs tested by at least this many rays resolve single-candidate trips together after the ray loop
 #ifndef RT_DEFER_MIN_RAYS
 #define RT_DEFER_MIN_RAYS 16
+#endif
+// single-precision pre-filter in front of the exact (run, ray) trips of primary rays; 0 switches it off
+#ifndef RT_PREFILTER
+#define RT_PREFILTER 1
 #endif
 // empty voxels a ray may cross in one round of wave_walk before the round goes on without it
 #ifndef RT_STEPS_PER_ROUND
@@ -1927,6 +1979,25 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             if (COUNT) { wc.lanes += (uint32_t)__popcll(have_m) * (uint32_t)__popcll(lm); wc.items += 1; wc.trips += (uint32_t)__popcll(lm); }
             wc.fb_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc.fb_items + 1u));      // a scalar register, not one per lane
             if (COUNT) { wc.loops[RT_LOOP_ITEMS] += 1; wc.loops[RT_LOOP_TRIPS] += (uint32_t)__popcll(lm); if (lm) wc.loops[RT_LOOP_ITEMS_WITH_RAYS] += 1; }
+            // Rays with a common origin first go through the single-precision pre-filter, two at a time; only those it cannot
+            // show to miss every triangle of the run take the exact trip below. Not in the variant for frames full of hits.
+            if (SHARED_ORIGIN && !DEFER && RT_PREFILTER && lm) {
+                const PreFilter pf = prefilter_setup(t, ox, oy, oz);
+                unsigned long long todo = 0ull, rest = lm;
+                while (rest) {
+                    const int i = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    const int j = rest ? __ffsll((long long)rest) - 1 : i;
+                    rest &= rest - 1;
+                    const rt_f2 rx = {bcast_f32(dx, i), bcast_f32(dx, j)}, ry = {bcast_f32(dy, i), bcast_f32(dy, j)}, rz = {bcast_f32(dz, i), bcast_f32(dz, j)};
+                    unsigned long long ki, kj;
+                    prefilter_pair(pf, rx, ry, rz, ki, kj);
+                    if (ki & have_m) todo |= 1ull << i;
+                    if (kj & have_m) todo |= 1ull << j;
+                }
+                if (COUNT) wc.loops[RT_LOOP_FILTER_KEPT] += (uint32_t)__popcll(todo);
+                lm = todo;
+            }
             if (lm) {
                 // origin-dependent terms, hoisted out of the ray loop when every ray has the same origin
                 double sx = 0, sy = 0, sz = 0, p_e2s = 0, p_e1s = 0;
