@@ -1554,6 +1554,7 @@ struct TriRec {
     double m12;              // e1.y*e2.z - e2.y*e1.z
     float f1x, f1y, f1z;     // v0 - v1 and v0 - v2 as stored (floats), for the single-precision pre-filter
     float f2x, f2y, f2z;
+    float w1, w2;            // fourth words of the record's second and third quarter (the halves of m12), as loaded
 };
 
 __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, const float4 r2) {
@@ -1563,6 +1564,7 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
     t.e2x = r2.x; t.e2y = r2.y; t.e2z = r2.z;
     t.f1x = r1.x; t.f1y = r1.y; t.f1z = r1.z;
     t.f2x = r2.x; t.f2y = r2.y; t.f2z = r2.z;
+    t.w1 = r1.w; t.w2 = r2.w;
     t.m12 = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(r2.w) << 32) | __float_as_uint(r1.w)));
     return t;
 }
@@ -1583,31 +1585,103 @@ __device__ __forceinline__ TriRec unpack_rec(const float4 r0, const float4 r1, c
 // or below, so nothing is dropped then. A ray keeps its exact trip (the double-precision test below, unchanged) whenever
 // any triangle of the run survives, so results are those of the exact test alone.
 typedef float rt_f2 __attribute__((ext_vector_type(2)));
+// Packed single-precision instructions (two results per lane) in which the first operand is ONE element of a register
+// pair, used for both results (H = 0: the low register, 1: the high one; the op_sel bits of the instruction), and the
+// second operand is a pair of scalar registers: the values of two rays. This way a triangle's numbers are used where
+// they already are (the halves of its record as loaded, pairs of normals) without duplicating them into pairs.
+template <int H>
+__device__ __forceinline__ rt_f2 pk_mul_h(rt_f2 a, rt_f2 rays) {
+    rt_f2 r;
+    if constexpr (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "s"(rays));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "s"(rays));
+    return r;
+}
+// a[H] * rays + c, or with NEG a[H] * rays - c
+template <int H, bool NEG = false>
+__device__ __forceinline__ rt_f2 pk_fma_h(rt_f2 a, rt_f2 rays, rt_f2 c) {
+    rt_f2 r;
+    if constexpr (H == 0 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(rays), "v"(c));
+    else if constexpr (H == 1 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "s"(rays), "v"(c));
+    else if constexpr (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "s"(rays), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "s"(rays), "v"(c));
+    return r;
+}
+// a[H] - rays
+template <int H>
+__device__ __forceinline__ rt_f2 pk_sub_h(rt_f2 a, rt_f2 rays) {
+    rt_f2 r;
+    if constexpr (H == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "s"(rays));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "s"(rays));
+    return r;
+}
+// lanes in which the three numbers of ray 0 (.x) and of ray 1 (.y) do not have definitely mixed signs: the largest above +E
+// and the smallest below -E is min(max3, -min3) > E (an ordered compare: a NaN keeps the lane)
+__device__ __forceinline__ void prefilter_keep(rt_f2 b, rt_f2 g, rt_f2 c, float E, unsigned long long& keep_i, unsigned long long& keep_j) {
+    const float mi = __builtin_fminf(__builtin_fmaxf(__builtin_fmaxf(b.x, g.x), c.x), -__builtin_fminf(__builtin_fminf(b.x, g.x), c.x));
+    const float mj = __builtin_fminf(__builtin_fmaxf(__builtin_fmaxf(b.y, g.y), c.y), -__builtin_fminf(__builtin_fminf(b.y, g.y), c.y));
+    keep_i = ~__builtin_amdgcn_fcmpf(mi, E, 2);
+    keep_j = ~__builtin_amdgcn_fcmpf(mj, E, 2);
+}
+// Rays with a common origin: the three normals s x e2, e1 x s and e1 x e2 - s x e2 - e1 x s and E, as five register pairs.
 struct PreFilter {
-    float nbx, nby, nbz, ngx, ngy, ngz, ncx, ncy, ncz, E;
+    rt_f2 n0, n1, n2, n3, n4;      // (nb.x, nb.y) (nb.z, ng.x) (ng.y, ng.z) (nc.x, nc.y) (nc.z, E)
 };
 __device__ __forceinline__ PreFilter prefilter_setup(const TriRec& t, float ox, float oy, float oz) {
     PreFilter f;
     const float sx = t.v0x - ox, sy = t.v0y - oy, sz = t.v0z - oz;
-    f.nbx = __builtin_fmaf(sy, t.f2z, -(sz * t.f2y)); f.nby = __builtin_fmaf(sz, t.f2x, -(sx * t.f2z)); f.nbz = __builtin_fmaf(sx, t.f2y, -(sy * t.f2x));
-    f.ngx = __builtin_fmaf(t.f1y, sz, -(t.f1z * sy)); f.ngy = __builtin_fmaf(t.f1z, sx, -(t.f1x * sz)); f.ngz = __builtin_fmaf(t.f1x, sy, -(t.f1y * sx));
+    const float nbx = __builtin_fmaf(sy, t.f2z, -(sz * t.f2y)), nby = __builtin_fmaf(sz, t.f2x, -(sx * t.f2z)), nbz = __builtin_fmaf(sx, t.f2y, -(sy * t.f2x));
+    const float ngx = __builtin_fmaf(t.f1y, sz, -(t.f1z * sy)), ngy = __builtin_fmaf(t.f1z, sx, -(t.f1x * sz)), ngz = __builtin_fmaf(t.f1x, sy, -(t.f1y * sx));
     const float nax = __builtin_fmaf(t.f1y, t.f2z, -(t.f1z * t.f2y)), nay = __builtin_fmaf(t.f1z, t.f2x, -(t.f1x * t.f2z)),
                 naz = __builtin_fmaf(t.f1x, t.f2y, -(t.f1y * t.f2x));
-    f.ncx = (nax - f.nbx) - f.ngx; f.ncy = (nay - f.nby) - f.ngy; f.ncz = (naz - f.nbz) - f.ngz;
     const float ls = fabsf(sx) + fabsf(sy) + fabsf(sz), l1 = fabsf(t.f1x) + fabsf(t.f1y) + fabsf(t.f1z), l2 = fabsf(t.f2x) + fabsf(t.f2y) + fabsf(t.f2z);
-    f.E = (l1 * l2 + ls * (l1 + l2)) * 7.2e-7f + 1e-30f;
+    f.n0 = (rt_f2){nbx, nby}; f.n1 = (rt_f2){nbz, ngx}; f.n2 = (rt_f2){ngy, ngz};
+    f.n3 = (rt_f2){(nax - nbx) - ngx, (nay - nby) - ngy};
+    f.n4 = (rt_f2){(naz - nbz) - ngz, (l1 * l2 + ls * (l1 + l2)) * 7.2e-7f + 1e-30f};
     return f;
 }
-// Lanes (triangles) that rays i and j cannot be shown to miss. dxi.. are the two rays' directions.
+// Lanes (triangles) that rays i and j cannot be shown to miss; (rx, ry, rz) hold the two rays' directions.
 __device__ __forceinline__ void prefilter_pair(const PreFilter& f, rt_f2 rx, rt_f2 ry, rt_f2 rz, unsigned long long& keep_i, unsigned long long& keep_j) {
-    const rt_f2 b = __builtin_elementwise_fma((rt_f2){f.nbz, f.nbz}, rz, __builtin_elementwise_fma((rt_f2){f.nby, f.nby}, ry, (rt_f2){f.nbx, f.nbx} * rx));
-    const rt_f2 g = __builtin_elementwise_fma((rt_f2){f.ngz, f.ngz}, rz, __builtin_elementwise_fma((rt_f2){f.ngy, f.ngy}, ry, (rt_f2){f.ngx, f.ngx} * rx));
-    const rt_f2 c = __builtin_elementwise_fma((rt_f2){f.ncz, f.ncz}, rz, __builtin_elementwise_fma((rt_f2){f.ncy, f.ncy}, ry, (rt_f2){f.ncx, f.ncx} * rx));
-    // the largest of the three above +E and the smallest below -E: min(max3, -min3) > E (ordered compare: a NaN keeps the lane)
-    const float mi = __builtin_fminf(__builtin_fmaxf(__builtin_fmaxf(b.x, g.x), c.x), -__builtin_fminf(__builtin_fminf(b.x, g.x), c.x));
-    const float mj = __builtin_fminf(__builtin_fmaxf(__builtin_fmaxf(b.y, g.y), c.y), -__builtin_fminf(__builtin_fminf(b.y, g.y), c.y));
-    keep_i = ~__builtin_amdgcn_fcmpf(mi, f.E, 2);
-    keep_j = ~__builtin_amdgcn_fcmpf(mj, f.E, 2);
+    const rt_f2 b = pk_fma_h<0>(f.n1, rz, pk_fma_h<1>(f.n0, ry, pk_mul_h<0>(f.n0, rx)));
+    const rt_f2 g = pk_fma_h<1>(f.n2, rz, pk_fma_h<0>(f.n2, ry, pk_mul_h<1>(f.n1, rx)));
+    const rt_f2 c = pk_fma_h<0>(f.n4, rz, pk_fma_h<1>(f.n3, ry, pk_mul_h<0>(f.n3, rx)));
+    prefilter_keep(b, g, c, f.n4.y, keep_i, keep_j);
+}
+// Rays with origins of their own (shadow rays): s = v0 - o differs from ray to ray, so the determinants are taken as
+//     bnum = s.(e2 x d),   gnum = s.(d x e1),   A = d.(e1 x e2),   cnum = A - bnum - gnum,
+// two rays per instruction, straight from the halves of the triangle's record. The same bound holds with |s|1 replaced
+// by |v0|1 + omax, omax = the largest |o|1 among the wavefront's rays. na = (e1 x e2).xy, nb = ((e1 x e2).z, E).
+struct PreFilterOwn {
+    rt_f2 v01, v2i, e1a, e1b, e2a, e2b, na, nb;
+};
+__device__ __forceinline__ PreFilterOwn prefilter_setup_own(const TriRec& t, float omax) {
+    PreFilterOwn f;
+    // the pairs are the record's halves in the registers they were loaded into
+    f.v01 = (rt_f2){t.v0x, t.v0y}; f.v2i = (rt_f2){t.v0z, __uint_as_float(t.id)};
+    f.e1a = (rt_f2){t.f1x, t.f1y}; f.e1b = (rt_f2){t.f1z, t.w1};
+    f.e2a = (rt_f2){t.f2x, t.f2y}; f.e2b = (rt_f2){t.f2z, t.w2};
+    const float nax = __builtin_fmaf(t.f1y, t.f2z, -(t.f1z * t.f2y)), nay = __builtin_fmaf(t.f1z, t.f2x, -(t.f1x * t.f2z)),
+                naz = __builtin_fmaf(t.f1x, t.f2y, -(t.f1y * t.f2x));
+    const float ls = (fabsf(t.v0x) + fabsf(t.v0y) + fabsf(t.v0z)) + omax, l1 = fabsf(t.f1x) + fabsf(t.f1y) + fabsf(t.f1z),
+                l2 = fabsf(t.f2x) + fabsf(t.f2y) + fabsf(t.f2z);
+    f.na = (rt_f2){nax, nay};
+    f.nb = (rt_f2){naz, (l1 * l2 + ls * (l1 + l2)) * 7.2e-7f + 1e-30f};
+    return f;
+}
+__device__ __forceinline__ void prefilter_pair_own(const PreFilterOwn& f, rt_f2 px, rt_f2 py, rt_f2 pz, rt_f2 rx, rt_f2 ry, rt_f2 rz,
+                                                   unsigned long long& keep_i, unsigned long long& keep_j) {
+    const rt_f2 sx = pk_sub_h<0>(f.v01, px), sy = pk_sub_h<1>(f.v01, py), sz = pk_sub_h<0>(f.v2i, pz);
+    // q = e2 x d, r = d x e1
+    const rt_f2 qx = pk_fma_h<1, true>(f.e2a, rz, pk_mul_h<0>(f.e2b, ry));       // e2.y d.z - e2.z d.y
+    const rt_f2 qy = pk_fma_h<0, true>(f.e2b, rx, pk_mul_h<0>(f.e2a, rz));       // e2.z d.x - e2.x d.z
+    const rt_f2 qz = pk_fma_h<0, true>(f.e2a, ry, pk_mul_h<1>(f.e2a, rx));       // e2.x d.y - e2.y d.x
+    const rt_f2 ux = pk_fma_h<0, true>(f.e1b, ry, pk_mul_h<1>(f.e1a, rz));       // d.y e1.z - d.z e1.y
+    const rt_f2 uy = pk_fma_h<0, true>(f.e1a, rz, pk_mul_h<0>(f.e1b, rx));       // d.z e1.x - d.x e1.z
+    const rt_f2 uz = pk_fma_h<1, true>(f.e1a, rx, pk_mul_h<0>(f.e1a, ry));       // d.x e1.y - d.y e1.x
+    const rt_f2 b = __builtin_elementwise_fma(sz, qz, __builtin_elementwise_fma(sy, qy, sx * qx));
+    const rt_f2 g = __builtin_elementwise_fma(sz, uz, __builtin_elementwise_fma(sy, uy, sx * ux));
+    const rt_f2 a = pk_fma_h<0>(f.nb, rz, pk_fma_h<1>(f.na, ry, pk_mul_h<0>(f.na, rx)));
+    const rt_f2 c = (a - b) - g;
+    prefilter_keep(b, g, c, f.nb.y, keep_i, keep_j);
 }
 
 // @phase other
@@ -1618,6 +1692,12 @@ __device__ __forceinline__ void prefilter_pair(const PreFilter& f, rt_f2 rx, rt_
 // single-precision pre-filter in front of the exact (run, ray) trips of primary rays; 0 switches it off
 #ifndef RT_PREFILTER
 #define RT_PREFILTER 1
+#endif
+// the same for rays with origins of their own (shadow rays). Off: it removes four of five exact trips of the shadow rays
+// and 4 % of the kernel's vector instructions, but its 46 instructions per pair of rays need more registers than the
+// test loop has (a record set is spilled per run) and the frame comes out 3 % slower with it.
+#ifndef RT_PREFILTER_OWN
+#define RT_PREFILTER_OWN 0
 #endif
 // empty voxels a ray may cross in one round of wave_walk before the round goes on without it
 #ifndef RT_STEPS_PER_ROUND
@@ -1700,6 +1780,12 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
     }
     bool hit = false;
     bool first = true;
+    // largest |o.x| + |o.y| + |o.z| among the wavefront's rays (error bound of the pre-filter for rays with origins of their own)
+    float omax = active ? fabsf(ox) + fabsf(oy) + fabsf(oz) : 0.f;
+    if (!SHARED_ORIGIN && !DEFER && RT_PREFILTER_OWN) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off));
+    }
     const double ddx = dx, ddy = dy, ddz = dz;
     const float ifx = (float)(1.0 / ddx), ify = (float)(1.0 / ddy), ifz = (float)(1.0 / ddz);     // for the per-run box test
     // @phase step
@@ -1759,21 +1845,28 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // the line is inside the box must overlap the one in which it is between the slab's planes. Box faces and slab
         // planes are moved outwards by mg = 4e-6 (8e-6 for the slab) * (largest |coordinate| of the box + |origin|), more
         // than 20 times the rounding error of the expressions below and of the stored bounds, so a line that touches a
-        // triangle of the run is always kept; fminf/fmaxf drop NaNs (0 * inf), which keeps the run as well, and so does a
-        // line parallel to the slab whose origin lies inside it (-inf .. +inf).
-        auto box_hit = [](const float4 q0, const float4 q1, const float4 q2, float rox, float roy, float roz, float rix, float riy, float riz,
-                          float rdx, float rdy, float rdz) -> bool {
-            const float mg = 4e-6f * (q0.w + (fabsf(rox) + fabsf(roy) + fabsf(roz))) + 1e-30f;
-            const float ax0 = ((q0.x - mg) - rox) * rix, ax1 = ((q1.x + mg) - rox) * rix;
-            const float ay0 = ((q0.y - mg) - roy) * riy, ay1 = ((q1.y + mg) - roy) * riy;
-            const float az0 = ((q0.z - mg) - roz) * riz, az1 = ((q1.z + mg) - roz) * riz;
-            const float n_o = q2.x * rox + q2.y * roy + q2.z * roz, n_d = q2.x * rdx + q2.y * rdy + q2.z * rdz;
+        // triangle of the run is always kept; fminf/fmaxf drop NaNs (0 * inf, inf - inf), which keeps the run as well, and
+        // so does a line parallel to the slab whose origin lies inside it (-inf .. +inf).
+        // A face at q is crossed at (q - o) / d, evaluated as fma(q, 1/d, -(o * 1/d)) with o * 1/d made once per ray:
+        // both forms round within 2 * 2^-24 * (|q| + |o|) / |d| of the exact value, a thirtieth of what mg moves the face by.
+        // roa = |o.x| + |o.y| + |o.z|; (rpx, rpy, rpz) = o * (1/d) per component.
+        auto box_hit = [](const float4 q0, const float4 q1, const float4 q2, float rox, float roy, float roz, float roa, float rpx, float rpy, float rpz,
+                          float rix, float riy, float riz, float rdx, float rdy, float rdz) -> bool {
+            const float mg = __builtin_fmaf(4e-6f, q0.w + roa, 1e-30f);
+            const float ax0 = __builtin_fmaf(q0.x - mg, rix, -rpx), ax1 = __builtin_fmaf(q1.x + mg, rix, -rpx);
+            const float ay0 = __builtin_fmaf(q0.y - mg, riy, -rpy), ay1 = __builtin_fmaf(q1.y + mg, riy, -rpy);
+            const float az0 = __builtin_fmaf(q0.z - mg, riz, -rpz), az1 = __builtin_fmaf(q1.z + mg, riz, -rpz);
+            const float n_o = __builtin_fmaf(q2.z, roz, __builtin_fmaf(q2.y, roy, q2.x * rox));
+            const float n_d = __builtin_fmaf(q2.z, rdz, __builtin_fmaf(q2.y, rdy, q2.x * rdx));
             const float inv = __builtin_amdgcn_rcpf(n_d);      // 1 ulp is far inside the margins; 0 gives inf like a division
-            const float s0 = ((q1.w - 2.f * mg) - n_o) * inv, s1 = ((q2.w + 2.f * mg) - n_o) * inv;
+            const float mg2 = mg + mg;
+            const float s0 = ((q1.w - mg2) - n_o) * inv, s1 = ((q2.w + mg2) - n_o) * inv;
             const float t0 = fmaxf(fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1)), fminf(s0, s1));
             const float t1 = fminf(fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1)), fmaxf(s0, s1));
             return !(t0 > t1);
         };
+        // what box_hit needs of a ray beside its origin and direction (a handful of operations per round, lane = ray)
+        const float oabs = fabsf(ox) + fabsf(oy) + fabsf(oz), opx = ox * ifx, opy = oy * ify, opz = oz * ifz;
         // (a) voxels with up to RT_CULL_LANE_RUNS runs: lane = ray, a short loop over the runs of its own voxel,
         //     all voxels of the round at once
         if (COUNT) {
@@ -1785,12 +1878,50 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 wc.loops[RT_LOOP_CULL_A_ROUNDS] += 1; wc.loops[RT_LOOP_CULL_A_ITER] += mx; wc.loops[RT_LOOP_CULL_A_LANES] += sm;
             }
         }
-        if (cull && nrun_me <= (cull_min >> 16)) {
-            const float4* bb = s.blk_bounds + 3ull * (org >> 6);
-            need0 = 0;
-#pragma unroll 4
-            for (uint32_t k = 0; k < nrun_me; ++k)
-                if (box_hit(bb[3 * k], bb[3 * k + 1], bb[3 * k + 2], ox, oy, oz, ifx, ify, ifz, dx, dy, dz)) need0 |= 1ull << k;
+        //     A round usually has a dozen such rays with half a dozen runs each: with lane = ray three quarters of the
+        //     wavefront would idle through every iteration. So the M rays are numbered and the 64 lanes dealt among them,
+        //     G = 64 >> ceil(log2 M) lanes per ray (as in the small-voxel path below): lane g * 2^lg + j tests runs g, g + G,
+        //     ... of ray j's voxel, the G partial masks are or-ed together and handed back to the ray's own lane.
+        {
+            const bool ca = cull && nrun_me <= (cull_min >> 16);
+            const unsigned long long cam = __ballot(ca);
+            const int M = __popcll(cam);
+            if (M > 32) {
+                if (ca) {
+                    const float4* bb = s.blk_bounds + 3ull * (org >> 6);
+                    need0 = 0;
+#pragma unroll 2
+                    for (uint32_t k = 0; k < nrun_me; ++k)
+                        if (box_hit(bb[3 * k], bb[3 * k + 1], bb[3 * k + 2], ox, oy, oz, oabs, opx, opy, opz, ifx, ify, ifz, dx, dy, dz)) need0 |= 1ull << k;
+                }
+            } else if (M > 0) {
+                const int lg = M <= 2 ? 1 : (M <= 4 ? 2 : (M <= 8 ? 3 : (M <= 16 ? 4 : 5)));
+                const uint32_t G = 64u >> lg;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                // place of this lane when the culling rays come first: a permutation of the 64 lanes
+                const int place = ca ? __popcll(cam & below) : M + __popcll(~cam & below);
+                const int by_place = __builtin_amdgcn_ds_permute(place << 2, lane);     // lane `place` receives this lane's number
+                const int j = lane & ((1 << lg) - 1);
+                const uint32_t g = (uint32_t)lane >> lg;
+                const int r = __shfl(by_place, j);                                      // the lane that holds ray j
+                const bool mine = j < M;
+                // (every lane takes part in every exchange: a lane that sat one out could not be read by the others)
+                const uint32_t h_org = (uint32_t)__shfl((int)org, r), h_nrun_r = (uint32_t)__shfl((int)nrun_me, r);
+                const uint32_t h_nrun = mine ? h_nrun_r : 0u;
+                const float hox = SHARED_ORIGIN ? ox : __shfl(ox, r), hoy = SHARED_ORIGIN ? oy : __shfl(oy, r), hoz = SHARED_ORIGIN ? oz : __shfl(oz, r);
+                const float hoa = SHARED_ORIGIN ? oabs : __shfl(oabs, r);
+                const float hpx = __shfl(opx, r), hpy = __shfl(opy, r), hpz = __shfl(opz, r);
+                const float hix = __shfl(ifx, r), hiy = __shfl(ify, r), hiz = __shfl(ifz, r);
+                const float hdx = __shfl(dx, r), hdy = __shfl(dy, r), hdz = __shfl(dz, r);
+                const float4* bb = s.blk_bounds + 3ull * (h_org >> 6);
+                uint32_t bits = 0;
+                for (uint32_t k = g; __ballot(k < h_nrun); k += G)
+                    if (k < h_nrun && box_hit(bb[3 * k], bb[3 * k + 1], bb[3 * k + 2], hox, hoy, hoz, hoa, hpx, hpy, hpz, hix, hiy, hiz, hdx, hdy, hdz)) bits |= 1u << k;
+                // or over the G lanes of a ray (lanes j, j + 2^lg, ...), then back to the ray's own lane from lane `place`
+                for (int off = 1 << lg; off < 64; off <<= 1) bits |= (uint32_t)__shfl_xor((int)bits, off);
+                const uint32_t mybits = (uint32_t)__shfl((int)bits, place);
+                if (ca) need0 = (unsigned long long)mybits;
+            }
         }
         // (b) more crowded voxels, one after the other: lane = run (up to 128 of them), the rays standing in the voxel
         //     are broadcast one by one; runs from 128 on are always tested
@@ -1816,10 +1947,12 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     // rays and leaves this loop
                     const float rox = SHARED_ORIGIN ? bcast_f32(ox, 0) : bcast_f32(ox, i), roy = SHARED_ORIGIN ? bcast_f32(oy, 0) : bcast_f32(oy, i),
                                 roz = SHARED_ORIGIN ? bcast_f32(oz, 0) : bcast_f32(oz, i);
+                    const float roa = SHARED_ORIGIN ? bcast_f32(oabs, 0) : bcast_f32(oabs, i);
+                    const float rpx = bcast_f32(opx, i), rpy = bcast_f32(opy, i), rpz = bcast_f32(opz, i);
                     const float rix = bcast_f32(ifx, i), riy = bcast_f32(ify, i), riz = bcast_f32(ifz, i);
                     const float rdx = bcast_f32(dx, i), rdy = bcast_f32(dy, i), rdz = bcast_f32(dz, i);
-                    const unsigned long long m0 = __ballot(h0 && box_hit(a0, a1, a2, rox, roy, roz, rix, riy, riz, rdx, rdy, rdz));
-                    const unsigned long long m1 = (vn > 64u) ? __ballot(h1 && box_hit(b0, b1, b2, rox, roy, roz, rix, riy, riz, rdx, rdy, rdz)) : 0ull;
+                    const unsigned long long m0 = __ballot(h0 && box_hit(a0, a1, a2, rox, roy, roz, roa, rpx, rpy, rpz, rix, riy, riz, rdx, rdy, rdz));
+                    const unsigned long long m1 = (vn > 64u) ? __ballot(h1 && box_hit(b0, b1, b2, rox, roy, roz, roa, rpx, rpy, rpz, rix, riy, riz, rdx, rdy, rdz)) : 0ull;
                     if (lane == i) { need0 = m0; need1 = m1; }
                     u0 |= m0; u1 |= m1;
                 }
@@ -1992,6 +2125,24 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     const rt_f2 rx = {bcast_f32(dx, i), bcast_f32(dx, j)}, ry = {bcast_f32(dy, i), bcast_f32(dy, j)}, rz = {bcast_f32(dz, i), bcast_f32(dz, j)};
                     unsigned long long ki, kj;
                     prefilter_pair(pf, rx, ry, rz, ki, kj);
+                    if (ki & have_m) todo |= 1ull << i;
+                    if (kj & have_m) todo |= 1ull << j;
+                }
+                if (COUNT) wc.loops[RT_LOOP_FILTER_KEPT] += (uint32_t)__popcll(todo);
+                lm = todo;
+            }
+            if (!SHARED_ORIGIN && !DEFER && RT_PREFILTER_OWN && lm) {
+                const PreFilterOwn pf = prefilter_setup_own(t, omax);
+                unsigned long long todo = 0ull, rest = lm;
+                while (rest) {
+                    const int i = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    const int j = rest ? __ffsll((long long)rest) - 1 : i;
+                    rest &= rest - 1;
+                    const rt_f2 px = {bcast_f32(ox, i), bcast_f32(ox, j)}, py = {bcast_f32(oy, i), bcast_f32(oy, j)}, pz = {bcast_f32(oz, i), bcast_f32(oz, j)};
+                    const rt_f2 rx = {bcast_f32(dx, i), bcast_f32(dx, j)}, ry = {bcast_f32(dy, i), bcast_f32(dy, j)}, rz = {bcast_f32(dz, i), bcast_f32(dz, j)};
+                    unsigned long long ki, kj;
+                    prefilter_pair_own(pf, px, py, pz, rx, ry, rz, ki, kj);
                     if (ki & have_m) todo |= 1ull << i;
                     if (kj & have_m) todo |= 1ull << j;
                 }
