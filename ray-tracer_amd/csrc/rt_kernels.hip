@@ -1460,6 +1460,17 @@ __device__ __forceinline__ unsigned long long bcast_u64(unsigned long long v, in
     const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), src_lane);
     return ((unsigned long long)hi << 32) | lo;
 }
+// Bitwise or of v over the 64 lanes, as a wavefront-uniform value: four shifts inside each row of 16 lanes, two row
+// broadcasts, then the last lane holds everything (data-parallel primitives of the vector unit: no memory, no LDS).
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);      // row_shr:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);      // row_shr:8
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);      // row_bcast:15
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);      // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ double bcast_f64(double v, int src_lane) {
     const long long b = __double_as_longlong(v);
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, src_lane);
@@ -2073,6 +2084,9 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     sk = 0;
                     sany0 = ~0ull; sany1 = ~0ull;
                     if (scull && snrun > (cull_min >> 16)) { sany0 = bcast_u64(any0, leader); sany1 = bcast_u64(any1, leader); }
+                    // voxels culled lane = ray: the runs that any ray standing in the voxel needs, so that the loop below goes
+                    // from needed run to needed run instead of asking the lanes about every run
+                    else if (scull) sany0 = (unsigned long long)wave_or_u32((at_voxel && cbeg == sb) ? (uint32_t)need0 : 0u);
                     if (COUNT) { wc.slots += 1; wc.loops[RT_LOOP_ITEMGEN_VOXELS] += 1; }
                 }
                 // crowded voxels: straight to the next run that some ray needs
