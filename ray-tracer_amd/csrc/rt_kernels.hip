@@ -1843,11 +1843,13 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // array, which is what the per-run boxes describe; a run is skipped for a ray when the ray's whole line misses
         // the run's box grown by a margin far above the rounding of this test and of the reference's double-precision
         // triangle test (NaNs keep the run). Small voxels start at their first record and usually fit one run.
-        // need[k>>6] bit (k&63) = this ray has to test run k of its voxel; runs from 128 on are always tested.
+        // need0 bit k = this ray has to test run k of its voxel; runs from 64 on (voxels of more than 4096 records) are always
+        // tested: a second word of bits costs the item generator, which every run of every voxel goes through, more than the
+        // culling of such voxels' far runs could save.
         const bool cull = alive && (cend - cbeg) >= (cull_min & 0xffffu);
         const uint32_t org = cull ? (cbeg & ~63u) : cbeg;
         const uint32_t nrun_me = (cend - org + 63u) >> 6;
-        unsigned long long need0 = ~0ull, need1 = ~0ull, any0 = ~0ull, any1 = ~0ull;
+        unsigned long long need0 = ~0ull, any0 = ~0ull;
         VoxelBest vb;                                    // passing triangles of this round's voxel (primary rays)
         vb_reset(vb);
         double pb_t = INFINITY;                          // RULE 1: nearest passing triangle beyond eps of this round's voxel
@@ -1934,8 +1936,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 if (ca) need0 = (unsigned long long)mybits;
             }
         }
-        // (b) more crowded voxels, one after the other: lane = run (up to 128 of them), the rays standing in the voxel
-        //     are broadcast one by one; runs from 128 on are always tested
+        // (b) more crowded voxels, one after the other: lane = run (the first 64 of them), the rays standing in the voxel
+        //     are broadcast one by one
         {
             unsigned long long dn = __ballot(cull && nrun_me > (cull_min >> 16));
             while (dn) {
@@ -1946,11 +1948,10 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 const unsigned long long mem = __ballot(cull && cbeg == vb);
                 dn &= ~mem;
                 if (COUNT) { wc.loops[RT_LOOP_CULL_B_VOXELS] += 1; wc.loops[RT_LOOP_CULL_B_RAYS] += (uint32_t)__popcll(mem); }
-                float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, b0 = a0, b1 = a0, b2 = a0;
-                const bool h0 = (uint32_t)lane < vn, h1 = (uint32_t)lane + 64u < vn;
+                float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
+                const bool h0 = (uint32_t)lane < vn;
                 if (h0) { const float4* q = s.blk_bounds + 3ull * (vo + lane); a0 = q[0]; a1 = q[1]; a2 = q[2]; }
-                if (h1) { const float4* q = s.blk_bounds + 3ull * (vo + 64u + lane); b0 = q[0]; b1 = q[1]; b2 = q[2]; }
-                unsigned long long lm = mem, u0 = 0, u1 = 0;
+                unsigned long long lm = mem, u0 = 0;
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
                     lm &= lm - 1;
@@ -1963,11 +1964,10 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     const float rix = bcast_f32(ifx, i), riy = bcast_f32(ify, i), riz = bcast_f32(ifz, i);
                     const float rdx = bcast_f32(dx, i), rdy = bcast_f32(dy, i), rdz = bcast_f32(dz, i);
                     const unsigned long long m0 = __ballot(h0 && box_hit(a0, a1, a2, rox, roy, roz, roa, rpx, rpy, rpz, rix, riy, riz, rdx, rdy, rdz));
-                    const unsigned long long m1 = (vn > 64u) ? __ballot(h1 && box_hit(b0, b1, b2, rox, roy, roz, roa, rpx, rpy, rpz, rix, riy, riz, rdx, rdy, rdz)) : 0ull;
-                    if (lane == i) { need0 = m0; need1 = m1; }
-                    u0 |= m0; u1 |= m1;
+                    if (lane == i) need0 = m0;
+                    u0 |= m0;
                 }
-                if (lane == leader) { any0 = u0; any1 = u1; }      // runs some ray of this voxel needs, kept in its first lane
+                if (lane == leader) any0 = u0;                     // runs some ray of this voxel needs, kept in its first lane
             }
         }
         // @phase own
@@ -2064,7 +2064,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // ---- TEST: the round's (voxel, needed run) items in order: voxels by their lowest lane, runs ascending. The
         // generator runs one item ahead of the tests so that the next run's records are in flight, also across voxels.
         uint32_t sb = 0, se = 0, sorg = 0, sk = 0, snrun = 0;
-        unsigned long long smem = 0, sany0 = ~0ull, sany1 = ~0ull;
+        unsigned long long smem = 0, sany0 = ~0ull;
         bool scull = false;
         struct Item { uint32_t base, b, e; unsigned long long rays; };
         auto next_item = [&](Item& it) -> bool {
@@ -2082,8 +2082,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     sorg = scull ? (sb & ~63u) : sb;
                     snrun = (se - sorg + 63u) >> 6;
                     sk = 0;
-                    sany0 = ~0ull; sany1 = ~0ull;
-                    if (scull && snrun > (cull_min >> 16)) { sany0 = bcast_u64(any0, leader); sany1 = bcast_u64(any1, leader); }
+                    sany0 = ~0ull;
+                    if (scull && snrun > (cull_min >> 16)) sany0 = bcast_u64(any0, leader);
                     // voxels culled lane = ray: the runs that any ray standing in the voxel needs, so that the loop below goes
                     // from needed run to needed run instead of asking the lanes about every run
                     else if (scull) sany0 = (unsigned long long)wave_or_u32((at_voxel && cbeg == sb) ? (uint32_t)need0 : 0u);
@@ -2094,14 +2094,10 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     const unsigned long long rest = sany0 & (~0ull << sk);
                     sk = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u;
                 }
-                if (sk >= 64u && sk < 128u) {
-                    const unsigned long long rest = sany1 & (~0ull << (sk - 64u));
-                    sk = rest ? 64u + (uint32_t)__ffsll((long long)rest) - 1u : 128u;
-                }
                 if (sk >= snrun) continue;
                 const uint32_t k = sk++;
                 unsigned long long rays = smem & __ballot(alive);       // shadow query: rays already hit need no more runs
-                if (scull && k < 128u) rays &= __ballot((((k < 64u) ? need0 : need1) >> (k & 63u)) & 1ull);
+                if (scull && k < 64u) rays &= __ballot((need0 >> k) & 1ull);
                 if (rays) { it.base = sorg + 64u * k; it.b = sb; it.e = se; it.rays = rays; return true; }
             }
         };
