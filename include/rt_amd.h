@@ -159,6 +159,13 @@ int rt_render_device_noalloc(rt_scene* s, const rt_params* p, void* d_rgb_f32, v
  * which set). A stream handed to a scene has to stay valid until the scene is destroyed or this call is made again.
  * Output buffers belong to the caller: frames in flight need one each. */
 int rt_scene_set_frames_in_flight(rt_scene* s, int32_t n);        /* 1..8 */
+/* Before it traces a frame the library estimates the cost of every 8x8 tile that sees the grid (sample rays walked
+ * through the grid, no triangle test) to order and size the work units of the render kernel; no pixel depends on the
+ * estimate. A frame with the camera, light, frame size, part and triangle list of the last estimated frame on its
+ * working set reuses that frame's numbers instead of estimating again (enable = 1, the default; RT_REUSE_ESTIMATE=0 in
+ * the environment of rt_scene_create() switches it off as well). enable = 0: every frame estimates. No counterpart in the
+ * reference. */
+int rt_scene_set_estimate_reuse(rt_scene* s, int32_t enable);
 int32_t rt_scene_frames_in_flight(const rt_scene* s);
 /* Up to n streams (hipStream_t, non-blocking) that really run side by side: the HIP runtime maps the streams of a process
  * onto a few hardware queues (four by default), and two streams on one queue execute in order. Each stream returned has

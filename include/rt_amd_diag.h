@@ -61,6 +61,10 @@ int rt_scene_unit_costs(rt_scene* s, uint32_t* out, int64_t n);
  * Synchronises the device. No counterpart in the reference. */
 int rt_loop_counts(uint64_t* out, int32_t n, int32_t reset);
 
+/* Frames of the scene so far that ran the tile cost estimate (the others reused an earlier frame's numbers, see
+ * rt_scene_set_estimate_reuse in rt_amd.h), or -1 for a NULL scene. No counterpart in the reference. */
+int64_t rt_scene_estimates_run(const rt_scene* s);
+
 /* What the render kernel of an earlier frame of the scene reported about its triangle tests: record runs streamed and
  * (run, ray) trips that found a candidate triangle, and whether the next frame would take the kernel variant that finishes
  * a run's hit trips together (it does from 12 such trips per run on; RT_DEFER=0/1 in the environment forces it). The

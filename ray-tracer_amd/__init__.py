@@ -82,7 +82,7 @@ EXPORTS = [
     "rt_last_error", "rt_version", "rt_params_default", "rt_part_rows",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_obj", "rt_scene_add_triangles", "rt_scene_add_obj_material", "rt_scene_add_triangles_material", "rt_scene_num_triangles",
     "rt_scene_get_triangles", "rt_scene_upload", "rt_scene_build_grid", "rt_scene_get_grid", "rt_scene_get_csr",
-    "rt_render_device", "rt_render_device_noalloc", "rt_scene_set_frames_in_flight", "rt_scene_frames_in_flight", "rt_streams_create", "rt_streams_destroy", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_triangle_order", "rt_scene_unit_costs", "rt_scene_test_feedback", "rt_loop_counts",
+    "rt_render_device", "rt_render_device_noalloc", "rt_scene_set_frames_in_flight", "rt_scene_frames_in_flight", "rt_streams_create", "rt_streams_destroy", "rt_render", "rt_render_ppm", "rt_scene_last_stats", "rt_scene_stats_at", "rt_scene_set_counting", "rt_scene_last_counts", "rt_scene_record_order", "rt_scene_triangle_order", "rt_scene_unit_costs", "rt_scene_test_feedback", "rt_loop_counts", "rt_scene_set_estimate_reuse", "rt_scene_estimates_run",
     "rt_deinterleave_device", "rt_selftest_division", "rt_comm_create", "rt_comm_destroy", "rt_comm_size", "rt_gather_bands",
     "rt_write_ppm", "rt_write_ppm_u8", "rt_make_plane_obj",
 ]
@@ -140,6 +140,9 @@ def lib():
     L.rt_scene_unit_costs.argtypes = [vp, vp, i64]
     L.rt_scene_test_feedback.argtypes = [vp, vp, vp, vp]
     L.rt_loop_counts.argtypes = [vp, i32, i32]
+    L.rt_scene_set_estimate_reuse.argtypes = [vp, i32]
+    L.rt_scene_estimates_run.argtypes = [vp]
+    L.rt_scene_estimates_run.restype = i64
     L.rt_render_device_noalloc.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rt_scene_set_frames_in_flight.argtypes = [vp, i32]
     L.rt_scene_frames_in_flight.argtypes = [vp]
@@ -321,6 +324,13 @@ class Scene:
 
     def set_counting(self, enable):
         _check(lib().rt_scene_set_counting(self.h, int(bool(enable))))
+
+    def estimates_run(self):
+        return int(lib().rt_scene_estimates_run(self.h))
+
+    def set_estimate_reuse(self, enable):
+        """Frames with the view and triangles of the last estimated frame skip the tile cost estimate (default on)."""
+        _check(lib().rt_scene_set_estimate_reuse(self.h, int(bool(enable))))
 
 
 def create_streams(n):

@@ -109,6 +109,12 @@ struct RtRenderWork {
     int32_t n_cu, blocks_per_cu;
     int32_t tx0, ntx, tb0, ntb;   // tile columns x local bands that may see the grid (conservative); the rest stays background
     unsigned long long* stamp_start;   // when not NULL, k_classify writes the real-time clock here (frame start of a frame without a build)
+    // Cost estimates kept from frame to frame: the estimate of every tile by tile number (may be NULL) and the total of the
+    // listed tiles' estimates. reuse_estimate = 1: this frame has the camera, the light and the triangles of the frame that
+    // left them there, so the estimate kernel is left out and the queue lists are made from the kept numbers.
+    uint32_t* cost_by_tile;
+    unsigned long long* kept_total;
+    int32_t reuse_estimate;
 };
 
 // Build-time scratch.

@@ -85,6 +85,13 @@ struct WorkSet {
     DevBuf<float4> recs, blk_bounds;
     DevBuf<unsigned long long> counters;   // 24 frame counters, the work-list words (RtRenderWork::work, 32 of them), 32 partial sums of the cost estimate, the dequeue heads
     DevBuf<uint32_t> tile_list, unit_cost, tile_cost, queue_lists;
+    // The cost estimate of every tile, by tile number, and the total, as the last frame with an estimate left them; est_key
+    // says for which frame they hold: the bytes of its parameters (camera, light, frame size, part) and the scene's version.
+    DevBuf<uint32_t> cost_by_tile;
+    DevBuf<unsigned long long> kept_total;
+    rt_params est_params;
+    uint64_t est_version = 0;
+    bool est_valid = false;
     bool zeroed = false;               // the fixed-size tables exist and were cleared for the current triangle list
     bool grid_valid = false;
     bool build_clean = false;          // the last grid build ran to its end and left its counters reset for the next one
@@ -99,6 +106,7 @@ struct WorkSet {
         d_grid.release(); bounds_enc.release(); cell_count.release(); cell_start.release(); block_sums.release(); occupancy.release();
         ref_tri.release(); ref_cell.release(); row_minmax.release(); recs.release(); blk_bounds.release(); counters.release();
         tile_list.release(); unit_cost.release(); tile_cost.release(); queue_lists.release();
+        cost_by_tile.release(); kept_total.release(); est_valid = false;
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side_stream) (void)hipStreamDestroy(side_stream);
@@ -155,6 +163,9 @@ struct rt_scene {
     int indexed_override = -1;               // RT_INDEXED_RECS: 0 / 1, -1 = the library decides
     int defer_override = -1;                 // RT_DEFER: 0 / 1, -1 = by the counts of earlier frames
     unsigned long long* feedback = nullptr;  // one word of pinned host memory the frames' kernels report to (RtBuildDev::feedback)
+    uint64_t version = 1;                    // goes up whenever the triangle list changes
+    bool reuse_estimate = true;              // frames with the camera, light and triangles of the set's last estimated frame skip the estimate
+    uint64_t estimates_run = 0;              // frames that ran the cost estimate
     void* noalloc_base = nullptr;            // this device's copy of the fixed working memory of rt_render_device_noalloc (looked up at upload)
     rt_params last_params;
     // experiment overrides, read once when the scene is created: RT_OWN_PATH (-1 = the library decides), RT_CULL_MIN
@@ -204,6 +215,7 @@ extern "C" rt_scene* rt_scene_create(void) {
         s->blocks_per_cu_cap = env_int("RT_BLOCKS_PER_CU", 1, 64, 0);
         s->force_sorted = env_int("RT_SORTED_BUILD", 0, 1, -1);
         s->side_stream_override = env_int("RT_SIDE_STREAM", 0, 1, -1);
+        s->reuse_estimate = env_int("RT_REUSE_ESTIMATE", 0, 1, 1) != 0;
         s->indexed_override = env_int("RT_INDEXED_RECS", 0, 1, -1);
         s->defer_override = env_int("RT_DEFER", 0, 1, -1);
         s->order_override = env_int("RT_TRI_ORDER", 0, 1, -1);
@@ -226,7 +238,8 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
 
 static void scene_touch(rt_scene* s) {
     s->uploaded = false; s->refs_known = false;
-    for (WorkSet& w : s->sets) { w.grid_valid = false; w.build_clean = false; }
+    s->version++;
+    for (WorkSet& w : s->sets) { w.grid_valid = false; w.build_clean = false; w.est_valid = false; }
 }
 
 // entry 1 of the Parallel tree's material table (Parallel/raytracer.cu:451) around a given colour
@@ -544,6 +557,8 @@ struct FrameMem {
     uint32_t *tile_list = nullptr, *tile_cost = nullptr, *queue_lists = nullptr;
     size_t tile_cap = 0;                     // tiles the three lists above can hold (queue_lists: RT_QUEUE_LISTS times as many)
     uint32_t* unit_cost = nullptr;           // counting frames only: 112 words per tile
+    uint32_t* cost_by_tile = nullptr;        // the tiles' cost estimates by tile number, kept from frame to frame (may be NULL)
+    unsigned long long* kept_total = nullptr;
     bool report = true;                      // the frame's counters feed the scene's choice of kernel variant (not when the memory is
                                              // shared with other scenes: the counters there may be another scene's)
 };
@@ -558,6 +573,7 @@ static FrameMem scene_mem(const rt_scene* s, const WorkSet& w, bool indexed = fa
     m.sorted = s->want_sorted();
     m.counters = w.counters.p;
     m.tile_list = w.tile_list.p; m.tile_cost = w.tile_cost.p; m.queue_lists = w.queue_lists.p; m.tile_cap = w.tile_list.cap;
+    m.cost_by_tile = w.cost_by_tile.cap >= w.tile_list.cap ? w.cost_by_tile.p : nullptr; m.kept_total = w.kept_total.p;
     m.unit_cost = w.unit_cost.p;
     return m;
 }
@@ -982,6 +998,15 @@ static size_t frame_tiles(const rt_params* p) {
 // enqueued on `st` in order and nothing but kernels and memsets is issued.
 // `build`: 0 = the grid in `m` is current, 1 = rebuild, the build state in `m` was left clean, 2 = rebuild from scratch.
 // `stamps` (may be NULL): four device words the kernels write the frame's times into, see rt_scene::stamps.
+// Do two frames see the scene the same way, as far as the tiles' cost estimates are concerned: camera, frame size, part of
+// the frame, and the light and eps the stand-in shadow rays of the estimate start from?
+static bool same_view(const rt_params& a, const rt_params& b) {
+    return a.width == b.width && a.height == b.height && a.part_index == b.part_index && a.part_count == b.part_count && a.fov == b.fov && a.eps == b.eps &&
+           a.walk_mode == b.walk_mode && a.shading_mode == b.shading_mode &&
+           memcmp(a.cam_pos, b.cam_pos, sizeof(a.cam_pos)) == 0 && memcmp(a.cam_target, b.cam_target, sizeof(a.cam_target)) == 0 &&
+           memcmp(a.cam_up, b.cam_up, sizeof(a.cam_up)) == 0 && memcmp(a.light_pos, b.light_pos, sizeof(a.light_pos)) == 0;
+}
+
 static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int build, WorkSet* ws, void* d_rgb_f32, void* d_rgb_u8, void* d_hit_id,
                         hipStream_t st, unsigned long long* stamps, bool* start_is_trace) {
     int rc;
@@ -1096,6 +1121,14 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
         wk.n_tiles = (int32_t)tiles;
         for (int k = 0; k < 4; ++k) wk.est_w[k] = s->est_w[k];
         wk.tile_list = m.tile_list;
+        // The cost estimate only orders and sizes the work units; no pixel depends on it. A frame with the camera, the light,
+        // the frame size and the triangles of the last frame that was estimated on this working set takes that frame's numbers.
+        wk.cost_by_tile = m.cost_by_tile; wk.kept_total = m.kept_total;
+        wk.reuse_estimate = 0;
+        if (ws && m.cost_by_tile && m.kept_total && !f.count_work) {
+            if (s->reuse_estimate && ws->est_valid && ws->est_version == s->version && same_view(ws->est_params, *p)) wk.reuse_estimate = 1;
+            else { ws->est_params = *p; ws->est_version = s->version; ws->est_valid = true; }
+        } else if (ws) ws->est_valid = false;
         // LDS for the occupancy bitmap: the grid of this triangle list was measured at upload
         wk.bitmap_words = (int32_t)((s->known_cells + 31) / 32);
         if (wk.bitmap_words < 1) wk.bitmap_words = 1;
@@ -1117,6 +1150,7 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
     const bool prep_runs = wk.ntx * wk.ntb > 0 && sd.n_tris != 0;
     wk.stamp_start = (build == 0 && prep_runs) ? stamps : nullptr;
     if (start_is_trace) *start_is_trace = build == 0 && !prep_runs;
+    if (prep_runs && !wk.reuse_estimate) s->estimates_run++;
     HIP_TRY(rt_launch_render_prep(sd, cam, sh, f, wk, side));
     if (side != st) {
         HIP_TRY(hipEventRecord(ws->ev_join, side));
@@ -1139,6 +1173,8 @@ extern "C" int rt_render_device(rt_scene* s, const rt_params* p, int rebuild_gri
     // working memory of the frame, grown when the triangle list or the frame size has grown
     const size_t tiles = frame_tiles(p);
     if ((rc = w->tile_list.ensure(tiles)) || (rc = w->tile_cost.ensure(tiles)) || (rc = w->queue_lists.ensure(tiles * RT_QUEUE_LISTS))) return rc;
+    if (w->cost_by_tile.cap < w->tile_list.cap) { w->est_valid = false; if ((rc = w->cost_by_tile.ensure(w->tile_list.cap))) return rc; }
+    if ((rc = w->kept_total.ensure(1))) return rc;
     if (s->count_work && (rc = w->unit_cost.ensure(tiles * 112))) return rc;
     if (rebuild && (rc = scene_ensure_refs(s, *w))) return rc;
     const int slot = (int)(s->frames % RT_STATS_RING);
@@ -1305,6 +1341,15 @@ extern "C" int64_t rt_selftest_division(const double* num, const double* den, in
     if (e != hipSuccess) return set_err(RT_ERR_HIP, "rt_selftest_division: %s", hipGetErrorString(e));
     return (int64_t)bad;
 }
+
+extern "C" int rt_scene_set_estimate_reuse(rt_scene* s, int32_t enable) {
+    if (!s) return set_err(RT_ERR_INVALID, "rt_scene_set_estimate_reuse: NULL scene");
+    s->reuse_estimate = enable != 0;
+    for (WorkSet& w : s->sets) w.est_valid = false;
+    return RT_OK;
+}
+
+extern "C" int64_t rt_scene_estimates_run(const rt_scene* s) { return s ? (int64_t)s->estimates_run : -1; }
 
 extern "C" int rt_scene_set_counting(rt_scene* s, int32_t enable) {
     if (!s) return set_err(RT_ERR_INVALID, "rt_scene_set_counting: NULL scene");

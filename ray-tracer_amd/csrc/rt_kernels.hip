@@ -1298,7 +1298,8 @@ __device__ __forceinline__ void estimate_walk(const RtSceneDev& s, const GridU& 
 // first repeats its primary ray up to the first occupied voxel. A wavefront then has one walk behind it instead of two.
 template <bool SPLIT>
 __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame f, const uint32_t* work, const uint32_t* tile_list,
-                                                  uint32_t* cost, unsigned long long* cost_sum, uint32_t* feat_by_tile, uint32_t n_tiles, float4 wgt) {
+                                                  uint32_t* cost, unsigned long long* cost_sum, uint32_t* feat_by_tile, uint32_t n_tiles, float4 wgt,
+                                                  uint32_t* cost_by_tile) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_raw);
     const uint32_t n = work[0];
@@ -1358,6 +1359,7 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
         const float e = wgt.x * (float)tp + wgt.y * (float)vp + wgt.z * (float)ts + wgt.w * (float)vs;
         c = e < 4.0e9f ? (uint32_t)e : 4000000000u;
         cost[i] = c;
+        if (cost_by_tile) cost_by_tile[tile] = c;      // kept for the frames after this one (same camera, same triangles)
         if (feat_by_tile) {
             feat_by_tile[tile] = tp; feat_by_tile[n_tiles + tile] = vp;
             feat_by_tile[2 * n_tiles + tile] = ts; feat_by_tile[3 * n_tiles + tile] = vs;
@@ -1380,7 +1382,9 @@ __global__ void __launch_bounds__(256) k_estimate(RtSceneDev s, RtCamera cam, Rt
 __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* tile_list, const uint32_t* cost,
                                                 const unsigned long long* cost_sum, uint32_t* lists, uint32_t cap,
                                                 float div0, float div1, int n_waves, unsigned long long unit_shifts, int adapt,
-                                                const RtGrid* grid) {
+                                                const RtGrid* grid, const uint32_t* cost_by_tile, unsigned long long* kept_total, int reuse) {
+    // reuse: no estimate ran for this frame; the tiles' costs are the ones an earlier frame with the same camera and the same
+    // triangles left in cost_by_tile, their total is in *kept_total
     const uint32_t n = work[0];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1405,15 +1409,19 @@ __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* 
         work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + threadIdx.x] = sh;
     }
     unsigned long long cost_total = 0;
+    if (reuse) cost_total = *kept_total;
+    else {
 #pragma unroll 8
-    for (uint32_t k = 0; k < RT_COST_SUM_PARTS; ++k) cost_total += cost_sum[k];
+        for (uint32_t k = 0; k < RT_COST_SUM_PARTS; ++k) cost_total += cost_sum[k];
+        if (kept_total && blockIdx.x == 0 && threadIdx.x == 0) *kept_total = cost_total;
+    }
     const float share = (float)((double)cost_total / (double)n_waves);
     const float lim0 = fmaxf(share / div0, 1.f), lim1 = fmaxf(share / div1, 0.5f);
     int cls = -1;
     uint32_t tile = 0;
     if (i < n) {
         tile = tile_list[i];
-        const float c = fmaxf((float)cost[i], 0.25f);
+        const float c = fmaxf((float)(reuse ? cost_by_tile[tile] : cost[i]), 0.25f);
         if (c >= lim0) {
             const int h = (int)(2.f * __log2f(c / lim0));
             cls = 7 - (h < 0 ? 0 : (h > 7 ? 7 : h));
@@ -2854,12 +2862,17 @@ hipError_t rt_launch_render_prep(RtSceneDev s, RtCamera cam, RtShade sh, RtFrame
     const int nb = (n_cls + 255) / 256;
     const float4 est_w = make_float4(wk.est_w[0], wk.est_w[1], wk.est_w[2], wk.est_w[3]);
     const size_t est_lds = (size_t)wk.bitmap_words * 4 + RT_EST_CELLS * 256 * 4;
-    if (s.n_tris <= RT_WIDE_MAX_TRIS)
-        k_estimate<true><<<(n_cls + 31) / 32, 256, est_lds, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles, est_w);
+    const int reuse = (wk.reuse_estimate && wk.cost_by_tile && wk.kept_total) ? 1 : 0;
+    if (reuse) {
+        // the tiles' costs of an earlier frame with this camera and these triangles stand: no estimate
+    } else if (s.n_tris <= RT_WIDE_MAX_TRIS)
+        k_estimate<true><<<(n_cls + 31) / 32, 256, est_lds, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles, est_w,
+                                                                   wk.cost_by_tile);
     else
-        k_estimate<false><<<(n_cls + 63) / 64, 256, est_lds, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles, est_w);
+        k_estimate<false><<<(n_cls + 63) / 64, 256, est_lds, st>>>(s, cam, sh, f, wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.est_by_tile, (uint32_t)wk.n_tiles, est_w,
+                                                                    wk.cost_by_tile);
     k_bucket<<<nb, 256, 0, st>>>(wk.work, wk.tile_list, wk.cost, wk.cost_sum, wk.lists, wk.list_cap, wk.thr0, wk.thr1, trace_blocks(f, wk) * RT_WAVES_PER_BLOCK,
-                                (unsigned long long)f.unit_shifts, f.adapt_units, s.grid);
+                                (unsigned long long)f.unit_shifts, f.adapt_units, s.grid, wk.cost_by_tile, wk.kept_total, reuse);
     return hipGetLastError();
 }
 

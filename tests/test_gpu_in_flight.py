@@ -114,3 +114,33 @@ def test_crowded_grid_in_flight(rt):
     finally:
         torch.cuda.synchronize()
         rt.destroy_streams(hs)
+
+
+@pytest.mark.gpu
+def test_cost_estimate_is_reused_only_for_the_same_view_and_changes_no_pixel(rt):
+    """A frame with the camera, light, frame size and triangles of the last estimated frame on its working set skips the
+    tile cost estimate; any change of the view or of the triangle list estimates again; the images are those of a scene
+    that estimates every frame (the estimate only orders and sizes the work units)."""
+    import numpy as np
+    from conftest import SPOT, BLUB
+    views = [dict(), dict(), dict(cam_pos=(2.5, 4.0, 3.5)), dict(cam_pos=(2.5, 4.0, 3.5)), dict(), dict(light_pos=(4.0, -5.0, 2.0)), dict(light_pos=(4.0, -5.0, 2.0))]
+    fresh = [True, False, True, False, True, True, False]
+    a = rt.Scene(); a.load_mesh(SPOT); a.load_mesh(BLUB, True, (255, 0, 0), (1.5, 0, 0))
+    b = rt.Scene(); b.load_mesh(SPOT); b.load_mesh(BLUB, True, (255, 0, 0), (1.5, 0, 0))
+    b.set_estimate_reuse(False)
+    for v, f in zip(views, fresh):
+        before = a.estimates_run()
+        p = rt.default_params(320, 240, **v)
+        ra, ua, ia = a.render(p, want_u8=True)
+        rb, ub, ib = b.render(p, want_u8=True)
+        assert a.estimates_run() - before == (1 if f else 0), (v, f)
+        assert np.array_equal(ia, ib) and np.array_equal(ra.view(np.uint32), rb.view(np.uint32)) and np.array_equal(ua, ub)
+    assert b.estimates_run() == len(views)
+    # another frame size, and a changed triangle list, estimate again
+    n0 = a.estimates_run()
+    a.render(rt.default_params(336, 240))
+    a.render(rt.default_params(336, 240))
+    assert a.estimates_run() == n0 + 1
+    a.load_mesh(SPOT, True, (0, 255, 0), (-1.5, 0, 0))
+    a.render(rt.default_params(336, 240))
+    assert a.estimates_run() == n0 + 2
