@@ -2356,9 +2356,9 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     Item N = P;
                     const bool hN = hP && next_item(N);
                     const uint32_t idxN = load_idx(N);
-                    gather(idxP, a0, a1, a2);
-                    itA = P; hA = hP; P = N; hP = hN; idxP = idxN;
                     process(cur, t);
+                    gather(idxP, a0, a1, a2);          // into the registers the test has just left: nothing is copied aside
+                    itA = P; hA = hP; P = N; hP = hN; idxP = idxN;
                 }
                 if (!hB) break;
                 {
@@ -2367,9 +2367,9 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     Item N = P;
                     const bool hN = hP && next_item(N);
                     const uint32_t idxN = load_idx(N);
+                    process(cur, t);
                     gather(idxP, b0, b1, b2);
                     itB = P; hB = hP; P = N; hP = hN; idxP = idxN;
-                    process(cur, t);
                 }
                 if (!hA) break;
             }
