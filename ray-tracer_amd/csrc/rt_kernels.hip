@@ -1641,28 +1641,39 @@ __device__ __forceinline__ void prefilter_keep(rt_f2 b, rt_f2 g, rt_f2 c, float 
     keep_i = ~__builtin_amdgcn_fcmpf(mi, E, 2);
     keep_j = ~__builtin_amdgcn_fcmpf(mj, E, 2);
 }
-// Rays with a common origin: the three normals s x e2, e1 x s and e1 x e2 - s x e2 - e1 x s and E, as five register pairs.
+// The x and y components of a x b in two packed instructions, from the pairs a01 = (a.x, a.y), a2 = (a.z, anything),
+// b01 = (b.x, b.y), b2 = (b.z, anything): (a.y b.z, -a.x b.z), then a.z (-b.y, b.x) added to it. Two roundings per component.
+__device__ __forceinline__ rt_f2 pk_cross_xy(rt_f2 a01, rt_f2 a2, rt_f2 b01, rt_f2 b2) {
+    rt_f2 t, c;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(t) : "v"(a01), "v"(b2));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]" : "=v"(c) : "v"(a2), "v"(b01), "v"(t));
+    return c;
+}
+// Rays with a common origin: the three normals nb = s x e2, ng = e1 x s, nc = e1 x e2 - nb - ng and E, as five register pairs.
 struct PreFilter {
-    rt_f2 n0, n1, n2, n3, n4;      // (nb.x, nb.y) (nb.z, ng.x) (ng.y, ng.z) (nc.x, nc.y) (nc.z, E)
+    rt_f2 n0, n1, n2, n3, n4;      // (nb.x, nb.y) (ng.x, ng.y) (nc.x, nc.y) (nb.z, ng.z) (nc.z, E)
 };
 __device__ __forceinline__ PreFilter prefilter_setup(const TriRec& t, float ox, float oy, float oz) {
     PreFilter f;
-    const float sx = t.v0x - ox, sy = t.v0y - oy, sz = t.v0z - oz;
-    const float nbx = __builtin_fmaf(sy, t.f2z, -(sz * t.f2y)), nby = __builtin_fmaf(sz, t.f2x, -(sx * t.f2z)), nbz = __builtin_fmaf(sx, t.f2y, -(sy * t.f2x));
-    const float ngx = __builtin_fmaf(t.f1y, sz, -(t.f1z * sy)), ngy = __builtin_fmaf(t.f1z, sx, -(t.f1x * sz)), ngz = __builtin_fmaf(t.f1x, sy, -(t.f1y * sx));
-    const float nax = __builtin_fmaf(t.f1y, t.f2z, -(t.f1z * t.f2y)), nay = __builtin_fmaf(t.f1z, t.f2x, -(t.f1x * t.f2z)),
-                naz = __builtin_fmaf(t.f1x, t.f2y, -(t.f1y * t.f2x));
+    // the record's halves as the pairs they were loaded as; s the same way (the second half of s2 is not a number anybody reads)
+    const rt_f2 e1a = {t.f1x, t.f1y}, e1b = {t.f1z, t.w1}, e2a = {t.f2x, t.f2y}, e2b = {t.f2z, t.w2};
+    const rt_f2 s01 = (rt_f2){t.v0x, t.v0y} - (rt_f2){ox, oy}, s2 = (rt_f2){t.v0z, __uint_as_float(t.id)} - (rt_f2){oz, 0.f};
+    const float sx = s01.x, sy = s01.y, sz = s2.x;
+    f.n0 = pk_cross_xy(s01, s2, e2a, e2b);
+    f.n1 = pk_cross_xy(e1a, e1b, s01, s2);
+    const rt_f2 na = pk_cross_xy(e1a, e1b, e2a, e2b);
+    f.n2 = (na - f.n0) - f.n1;
+    const float nbz = __builtin_fmaf(sx, t.f2y, -(sy * t.f2x)), ngz = __builtin_fmaf(t.f1x, sy, -(t.f1y * sx)), naz = __builtin_fmaf(t.f1x, t.f2y, -(t.f1y * t.f2x));
     const float ls = fabsf(sx) + fabsf(sy) + fabsf(sz), l1 = fabsf(t.f1x) + fabsf(t.f1y) + fabsf(t.f1z), l2 = fabsf(t.f2x) + fabsf(t.f2y) + fabsf(t.f2z);
-    f.n0 = (rt_f2){nbx, nby}; f.n1 = (rt_f2){nbz, ngx}; f.n2 = (rt_f2){ngy, ngz};
-    f.n3 = (rt_f2){(nax - nbx) - ngx, (nay - nby) - ngy};
+    f.n3 = (rt_f2){nbz, ngz};
     f.n4 = (rt_f2){(naz - nbz) - ngz, (l1 * l2 + ls * (l1 + l2)) * 7.2e-7f + 1e-30f};
     return f;
 }
 // Lanes (triangles) that rays i and j cannot be shown to miss; (rx, ry, rz) hold the two rays' directions.
 __device__ __forceinline__ void prefilter_pair(const PreFilter& f, rt_f2 rx, rt_f2 ry, rt_f2 rz, unsigned long long& keep_i, unsigned long long& keep_j) {
-    const rt_f2 b = pk_fma_h<0>(f.n1, rz, pk_fma_h<1>(f.n0, ry, pk_mul_h<0>(f.n0, rx)));
-    const rt_f2 g = pk_fma_h<1>(f.n2, rz, pk_fma_h<0>(f.n2, ry, pk_mul_h<1>(f.n1, rx)));
-    const rt_f2 c = pk_fma_h<0>(f.n4, rz, pk_fma_h<1>(f.n3, ry, pk_mul_h<0>(f.n3, rx)));
+    const rt_f2 b = pk_fma_h<0>(f.n3, rz, pk_fma_h<1>(f.n0, ry, pk_mul_h<0>(f.n0, rx)));
+    const rt_f2 g = pk_fma_h<1>(f.n3, rz, pk_fma_h<1>(f.n1, ry, pk_mul_h<0>(f.n1, rx)));
+    const rt_f2 c = pk_fma_h<0>(f.n4, rz, pk_fma_h<1>(f.n2, ry, pk_mul_h<0>(f.n2, rx)));
     prefilter_keep(b, g, c, f.n4.y, keep_i, keep_j);
 }
 // Rays with origins of their own (shadow rays): s = v0 - o differs from ray to ray, so the determinants are taken as
