@@ -7,10 +7,10 @@ for w in "$@"; do
   for mode in "" one_at_a_time; do
     tag=${w}${mode:+_$mode}; flag=""; [ -n "$mode" ] && flag="--in-flight 1"
     cd /tmp
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_$tag -o $w -- python3 $R/bench.py --no-cpu --no-extras --workload $w --steps 40 $flag > $R/gpurun_out/final/${ROUND:-r02}_final_${tag}_bench.json 2> $R/gpurun_out/final/$tag.err || { tail -5 $R/gpurun_out/final/$tag.err; exit 1; }
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_$tag -o $w -- python3 $R/bench.py --no-cpu --no-extras --workload $w --steps 40 $flag > $R/gpurun_out/final/${ROUND:-r03}_final_${tag}_bench.json 2> $R/gpurun_out/final/$tag.err || { tail -5 $R/gpurun_out/final/$tag.err; exit 1; }
     cd $R
     f=$(ls gpurun_out/final/prof_$tag/*kernel_stats.csv gpurun_out/final/prof_$tag/*/*kernel_stats.csv 2>/dev/null | head -1)
-    cp $f gpurun_out/final/${ROUND:-r02}_final_${tag}_kernel_stats.csv
-    head -4 gpurun_out/final/${ROUND:-r02}_final_${tag}_kernel_stats.csv | cut -c1-90
+    cp $f gpurun_out/final/${ROUND:-r03}_final_${tag}_kernel_stats.csv
+    head -4 gpurun_out/final/${ROUND:-r03}_final_${tag}_kernel_stats.csv | cut -c1-90
   done
 done
