@@ -1724,8 +1724,8 @@ __device__ __forceinline__ void prefilter_pair_own(const PreFilterOwn& f, rt_f2 
 #define RT_PREFILTER 1
 #endif
 // the same for rays with origins of their own (shadow rays). Off: it removes four of five exact trips of the shadow rays
-// and 4 % of the kernel's vector instructions, but its 46 instructions per pair of rays need more registers than the
-// test loop has (a record set is spilled per run) and the frame comes out 3 % slower with it.
+// and 3 % of the kernel's vector instructions (46 per pair of rays instead of 47 per ray), adds as many scalar ones and
+// a few spilled registers per run, and the frame comes out within 1 % of what it is without (slower, if anything).
 #ifndef RT_PREFILTER_OWN
 #define RT_PREFILTER_OWN 0
 #endif
