@@ -1228,6 +1228,81 @@ __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t
     return go;
 }
 
+// empty voxels a ray may cross in one round of wave_walk before the round goes on without it
+#ifndef RT_STEPS_PER_ROUND
+#define RT_STEPS_PER_ROUND 8
+#endif
+// The empty-voxel loop of the walk for a whole wavefront, scheduled by hand: every lane in `moving` whose voxel is empty
+// takes dda_advance steps (same selections, same additions, so the same state to the bit) until it stands at an occupied
+// voxel, has taken RT_STEPS_PER_ROUND steps, or is done (leaves the grid, or has a hit nearer than `lim` where `no_early`
+// does not hold its bit); the lanes that are done come back as a mask. Why by hand: written as a loop over dda_advance the
+// compiler spends 33 scalar instructions per voxel on saving, narrowing and restoring the execution mask around the
+// loop's two exit conditions and the axis selects; here the three axes are updated under three execution masks (an
+// addition, a count-down and an index step each) and the loop keeps one mask of the lanes still stepping.
+// A compare that writes scalar registers is followed by two other instructions before a vector instruction reads them.
+__device__ __forceinline__ unsigned long long step_through_empty(Dda& w, const uint32_t* bitmap, float lim, unsigned long long no_early,
+                                                                 unsigned long long moving) {
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)bitmap;
+    unsigned long long done, saved, c01, go, tm, t0s_dummy;
+    uint32_t t0, t1, t2;
+    int cnt;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_mov_b64 %[done], 0\n\t"
+        "s_and_b64 exec, exec, %[moving]\n\t"
+        "s_movk_i32 %[cnt], %[steps]\n\t"
+        "s_cbranch_execz .Lstep_end%=\n"
+        ".Lstep_loop%=:\n\t"
+        "v_cmp_lt_f32_e64 %[c01], %[n0], %[n1]\n\t"
+        "v_lshrrev_b32_e32 %[t0], 5, %[cell]\n\t"
+        "v_lshl_add_u32 %[t0], %[t0], 2, %[base]\n\t"
+        "v_cndmask_b32_e64 %[t1], %[n1], %[n0], %[c01]\n\t"        // the nearer crossing of axes 0 and 1 (axis 1 on a tie)
+        "ds_read_b32 %[t0], %[t0]\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[t1], %[n2]\n\t"                    // ... is nearer than that of axis 2 (axis 2 on a tie)
+        "v_cndmask_b32_e64 %[t2], %[l1], %[l0], %[c01]\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_e32 %[t1], %[n2], %[t1], vcc\n\t"             // t1: crossing into the next voxel
+        "v_cndmask_b32_e32 %[t2], %[l2], %[t2], vcc\n\t"             // t2: steps left along the axis of that crossing
+        "v_cmp_nlt_f32_e64 %[go], %[lim], %[t1]\n\t"                // no hit nearer than the crossing ...
+        "v_cmp_ne_u32_e64 %[tm], 0, %[t2]\n\t"                      // ... and not in the last voxel of the axis
+        "s_or_b64 %[go], %[go], %[noearly]\n\t"
+        "s_and_b64 %[go], %[go], %[tm]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[t0], %[t0], %[cell], 1\n\t"                    // the voxel's bit (offset = the low five bits of the index)
+        "v_cmp_eq_u32_e64 %[tm], 0, %[t0]\n\t"                      // lanes at an empty voxel
+        "s_andn2_b64 %[t0s], %[tm], %[go]\n\t"                      // of them: done
+        "s_and_b64 %[go], %[tm], %[go]\n\t"                         //          stepping on
+        "s_or_b64 %[done], %[done], %[t0s]\n\t"
+        "s_and_b64 %[t0s], %[c01], vcc\n\t"                         // along axis 0
+        "s_and_b64 exec, %[t0s], %[go]\n\t"
+        "v_add_f32_e32 %[n0], %[n0], %[d0]\n\t"
+        "v_add_u32_e32 %[l0], -1, %[l0]\n\t"
+        "v_add_u32_e32 %[cell], %[cell], %[c0]\n\t"
+        "s_andn2_b64 %[t0s], vcc, %[c01]\n\t"                       // along axis 1
+        "s_and_b64 exec, %[t0s], %[go]\n\t"
+        "v_add_f32_e32 %[n1], %[n1], %[d1]\n\t"
+        "v_add_u32_e32 %[l1], -1, %[l1]\n\t"
+        "v_add_u32_e32 %[cell], %[cell], %[c1]\n\t"
+        "s_andn2_b64 exec, %[go], vcc\n\t"                          // along axis 2
+        "v_add_f32_e32 %[n2], %[n2], %[d2]\n\t"
+        "v_add_u32_e32 %[l2], -1, %[l2]\n\t"
+        "v_add_u32_e32 %[cell], %[cell], %[c2]\n\t"
+        "s_mov_b64 exec, %[go]\n\t"
+        "s_cbranch_execz .Lstep_end%=\n\t"
+        "s_add_i32 %[cnt], %[cnt], -1\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 .Lstep_loop%=\n"
+        ".Lstep_end%=:\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [cell] "+v"(w.cell), [n0] "+v"(w.next0), [n1] "+v"(w.next1), [n2] "+v"(w.next2), [l0] "+v"(w.left0), [l1] "+v"(w.left1), [l2] "+v"(w.left2),
+          [done] "=&s"(done), [saved] "=&s"(saved), [c01] "=&s"(c01), [go] "=&s"(go), [tm] "=&s"(tm), [t0s] "=&s"(t0s_dummy),
+          [cnt] "=&s"(cnt), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [d0] "v"(w.delta0), [d1] "v"(w.delta1), [d2] "v"(w.delta2), [c0] "v"(w.cstep0), [c1] "v"(w.cstep1), [c2] "v"(w.cstep2),
+          [lim] "v"(lim), [base] "s"(base), [noearly] "s"(no_early), [moving] "s"(moving), [steps] "n"(RT_STEPS_PER_ROUND)
+        : "vcc", "scc");
+    return done;
+}
+
 // @phase kernel_setup
 // Occupancy bitmap of the grid into LDS, all loads of a thread in flight together (16 bytes each).
 __device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* occupancy, int words) {
@@ -1719,6 +1794,10 @@ __device__ __forceinline__ void prefilter_pair_own(const PreFilterOwn& f, rt_f2 
 #ifndef RT_DEFER_MIN_RAYS
 #define RT_DEFER_MIN_RAYS 16
 #endif
+// the empty-voxel loop of the walk as hand-scheduled instructions (step_through_empty); 0: the loop the compiler makes of dda_advance
+#ifndef RT_STEP_BY_HAND
+#define RT_STEP_BY_HAND 1
+#endif
 // single-precision pre-filter in front of the exact (run, ray) trips of primary rays; 0 switches it off
 #ifndef RT_PREFILTER
 #define RT_PREFILTER 1
@@ -1728,10 +1807,6 @@ __device__ __forceinline__ void prefilter_pair_own(const PreFilterOwn& f, rt_f2 
 // a few spilled registers per run, and the frame comes out within 1 % of what it is without (slower, if anything).
 #ifndef RT_PREFILTER_OWN
 #define RT_PREFILTER_OWN 0
-#endif
-// empty voxels a ray may cross in one round of wave_walk before the round goes on without it
-#ifndef RT_STEPS_PER_ROUND
-#define RT_STEPS_PER_ROUND 8
 #endif
 // voxels of up to this many records are tested apart from the streamed runs, by the lanes dealt to the rays standing in
 // them, when at least RT_OWN_MIN_RAYS rays of the wavefront stand in such voxels; 0 switches the path off
@@ -1840,10 +1915,15 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             for (int off = 32; off > 0; off >>= 1) it = max(it, (uint32_t)__shfl_xor((int)it, off));
             wc.loops[RT_LOOP_STEP_ITER] += it;
         }
-        while (alive && !((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u) && steps_left > 0) {
-            alive = dda_advance(w, early && hit, st.t, slack);
-            if (COUNT && alive) ++wc.steps;
-            --steps_left;
+        if (COUNT || !RT_STEP_BY_HAND) {
+            while (alive && !((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u) && steps_left > 0) {
+                alive = dda_advance(w, early && hit, st.t, slack);
+                if (COUNT && alive) ++wc.steps;
+                --steps_left;
+            }
+        } else {
+            const unsigned long long done = step_through_empty(w, bitmap, st.t + fabsf(st.t) * slack, __ballot(!(early && hit)), __ballot(alive));
+            alive = alive && !__builtin_amdgcn_inverse_ballot_w64(done);
         }
         if (!__ballot(alive)) break;
         const bool at_voxel = alive && ((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u);
