@@ -1303,6 +1303,50 @@ __device__ __forceinline__ unsigned long long step_through_empty(Dda& w, const u
     return done;
 }
 
+// One dda_advance step for the lanes in `moving`, in the same form; returns the lanes that are done.
+__device__ __forceinline__ unsigned long long step_once(Dda& w, float lim, unsigned long long no_early, unsigned long long moving) {
+    unsigned long long done, saved, c01, go, tm;
+    uint32_t t1, t2;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_and_b64 exec, exec, %[moving]\n\t"
+        "v_cmp_lt_f32_e64 %[c01], %[n0], %[n1]\n\t"
+        "s_mov_b64 %[done], exec\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_e64 %[t1], %[n1], %[n0], %[c01]\n\t"
+        "v_cndmask_b32_e64 %[t2], %[l1], %[l0], %[c01]\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[t1], %[n2]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[t1], %[n2], %[t1], vcc\n\t"
+        "v_cndmask_b32_e32 %[t2], %[l2], %[t2], vcc\n\t"
+        "v_cmp_nlt_f32_e64 %[go], %[lim], %[t1]\n\t"
+        "v_cmp_ne_u32_e64 %[tm], 0, %[t2]\n\t"
+        "s_or_b64 %[go], %[go], %[noearly]\n\t"
+        "s_and_b64 %[go], %[go], %[tm]\n\t"
+        "s_andn2_b64 %[done], %[done], %[go]\n\t"
+        "s_and_b64 %[tm], %[c01], vcc\n\t"
+        "s_and_b64 exec, %[tm], %[go]\n\t"
+        "v_add_f32_e32 %[n0], %[n0], %[d0]\n\t"
+        "v_add_u32_e32 %[l0], -1, %[l0]\n\t"
+        "v_add_u32_e32 %[cell], %[cell], %[c0]\n\t"
+        "s_andn2_b64 %[tm], vcc, %[c01]\n\t"
+        "s_and_b64 exec, %[tm], %[go]\n\t"
+        "v_add_f32_e32 %[n1], %[n1], %[d1]\n\t"
+        "v_add_u32_e32 %[l1], -1, %[l1]\n\t"
+        "v_add_u32_e32 %[cell], %[cell], %[c1]\n\t"
+        "s_andn2_b64 exec, %[go], vcc\n\t"
+        "v_add_f32_e32 %[n2], %[n2], %[d2]\n\t"
+        "v_add_u32_e32 %[l2], -1, %[l2]\n\t"
+        "v_add_u32_e32 %[cell], %[cell], %[c2]\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [cell] "+v"(w.cell), [n0] "+v"(w.next0), [n1] "+v"(w.next1), [n2] "+v"(w.next2), [l0] "+v"(w.left0), [l1] "+v"(w.left1), [l2] "+v"(w.left2),
+          [done] "=&s"(done), [saved] "=&s"(saved), [c01] "=&s"(c01), [go] "=&s"(go), [tm] "=&s"(tm), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [d0] "v"(w.delta0), [d1] "v"(w.delta1), [d2] "v"(w.delta2), [c0] "v"(w.cstep0), [c1] "v"(w.cstep1), [c2] "v"(w.cstep2),
+          [lim] "v"(lim), [noearly] "s"(no_early), [moving] "s"(moving)
+        : "vcc", "scc");
+    return done;
+}
+
 // @phase kernel_setup
 // Occupancy bitmap of the grid into LDS, all loads of a thread in flight together (16 bytes each).
 __device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* occupancy, int words) {
@@ -1898,9 +1942,16 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // ---- STEP: on to the next occupied voxel
         const long long t0 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (COUNT && __ballot(alive && !first)) wc.loops[RT_LOOP_ADVANCE] += 1;
-        if (alive && !first) {
-            alive = dda_advance(w, early && hit, st.t, slack);
-            if (COUNT && alive) ++wc.steps;
+        const float lim = st.t + fabsf(st.t) * slack;
+        const unsigned long long no_early = __ballot(!(early && hit));
+        if (COUNT || !RT_STEP_BY_HAND) {
+            if (alive && !first) {
+                alive = dda_advance(w, early && hit, st.t, slack);
+                if (COUNT && alive) ++wc.steps;
+            }
+        } else {
+            const unsigned long long adv = __ballot(alive && !first);
+            if (adv) alive = alive && !__builtin_amdgcn_inverse_ballot_w64(step_once(w, lim, no_early, adv));
         }
         // at most RT_STEPS_PER_ROUND empty voxels per round: a ray on a long empty stretch goes on in the next round
         // instead of keeping the others waiting (it takes part in this round with an empty voxel)
@@ -1922,7 +1973,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 --steps_left;
             }
         } else {
-            const unsigned long long done = step_through_empty(w, bitmap, st.t + fabsf(st.t) * slack, __ballot(!(early && hit)), __ballot(alive));
+            const unsigned long long done = step_through_empty(w, bitmap, lim, no_early, __ballot(alive));
             alive = alive && !__builtin_amdgcn_inverse_ballot_w64(done);
         }
         if (!__ballot(alive)) break;
