@@ -2213,41 +2213,43 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // @phase itemgen
         // ---- TEST: the round's (voxel, needed run) items in order: voxels by their lowest lane, runs ascending. The
         // generator runs one item ahead of the tests so that the next run's records are in flight, also across voxels.
-        uint32_t sb = 0, se = 0, sorg = 0, sk = 0, snrun = 0;
-        unsigned long long smem = 0, sany0 = ~0ull;
-        bool scull = false;
+        uint32_t sb = 0, se = 0, sorg = 0, sextra = 0, sextra_end = 0;
+        unsigned long long smem = 0, srest = 0;                 // rays of the open voxel; its runs below 64 still to visit
         struct Item { uint32_t base, b, e; unsigned long long rays; };
         auto next_item = [&](Item& it) -> bool {
             if (COUNT) wc.loops[RT_LOOP_ITEMGEN_CALLS] += 1;
             for (;;) {
                 if (COUNT) wc.loops[RT_LOOP_ITEMGEN_ITER] += 1;
-                if (sk >= snrun) {
+                uint32_t k;
+                unsigned long long rays = smem;
+                if (srest) {
+                    // straight to the next run that some ray needs
+                    k = (uint32_t)__ffsll((long long)srest) - 1u;
+                    srest &= srest - 1ull;
+                    rays &= __ballot((need0 >> k) & 1ull);
+                } else if (sextra < sextra_end) {
+                    k = sextra++;                               // runs from 64 on (voxels of more than 4096 records): every ray
+                } else {
                     if (!un) return false;
                     const int leader = __ffsll((long long)un) - 1;
                     sb = (uint32_t)__builtin_amdgcn_readlane((int)cbeg, leader);
                     se = (uint32_t)__builtin_amdgcn_readlane((int)cend, leader);
                     smem = __ballot(at_voxel && cbeg == sb);
                     un &= ~smem;
-                    scull = (se - sb) >= (cull_min & 0xffffu);
+                    const bool scull = (se - sb) >= (cull_min & 0xffffu);
                     sorg = scull ? (sb & ~63u) : sb;
-                    snrun = (se - sorg + 63u) >> 6;
-                    sk = 0;
-                    sany0 = ~0ull;
+                    const uint32_t snrun = (se - sorg + 63u) >> 6;
+                    unsigned long long sany0 = ~0ull;
                     if (scull && snrun > (cull_min >> 16)) sany0 = bcast_u64(any0, leader);
-                    // voxels culled lane = ray: the runs that any ray standing in the voxel needs, so that the loop below goes
+                    // voxels culled lane = ray: the runs that any ray standing in the voxel needs, so that the generator goes
                     // from needed run to needed run instead of asking the lanes about every run
                     else if (scull) sany0 = (unsigned long long)wave_or_u32((at_voxel && cbeg == sb) ? (uint32_t)need0 : 0u);
+                    srest = snrun < 64u ? sany0 & ((1ull << snrun) - 1ull) : sany0;
+                    sextra = 64u; sextra_end = snrun;
                     if (COUNT) { wc.slots += 1; wc.loops[RT_LOOP_ITEMGEN_VOXELS] += 1; }
+                    continue;
                 }
-                // crowded voxels: straight to the next run that some ray needs
-                if (sk < 64u) {
-                    const unsigned long long rest = sany0 & (~0ull << sk);
-                    sk = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u;
-                }
-                if (sk >= snrun) continue;
-                const uint32_t k = sk++;
-                unsigned long long rays = smem & __ballot(alive);       // shadow query: rays already hit need no more runs
-                if (scull && k < 64u) rays &= __ballot((need0 >> k) & 1ull);
+                if (ANY_HIT) rays &= __ballot(alive);           // shadow query: rays already hit need no more runs
                 if (rays) { it.base = sorg + 64u * k; it.b = sb; it.e = se; it.rays = rays; return true; }
             }
         };
