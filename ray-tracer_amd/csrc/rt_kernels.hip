@@ -1846,11 +1846,12 @@ __device__ __forceinline__ void prefilter_pair_own(const PreFilterOwn& f, rt_f2 
 #ifndef RT_PREFILTER
 #define RT_PREFILTER 1
 #endif
-// the same for rays with origins of their own (shadow rays). Off: it removes four of five exact trips of the shadow rays
-// and 3 % of the kernel's vector instructions (46 per pair of rays instead of 47 per ray), adds as many scalar ones and
-// a few spilled registers per run, and the frame comes out within 1 % of what it is without (slower, if anything).
+// the same for rays with origins of their own (shadow rays): removes four of five of their exact trips and 3 % of the
+// kernel's vector instructions (46 per pair of rays instead of 47 per ray) and adds as many scalar ones. With frames in
+// flight the GPU is bound by vector issue, and the frame rate follows the vector count (1.5 %); one frame at a time
+// nothing changes.
 #ifndef RT_PREFILTER_OWN
-#define RT_PREFILTER_OWN 0
+#define RT_PREFILTER_OWN 1
 #endif
 // voxels of up to this many records are tested apart from the streamed runs, by the lanes dealt to the rays standing in
 // them, when at least RT_OWN_MIN_RAYS rays of the wavefront stand in such voxels; 0 switches the path off
