@@ -5,9 +5,14 @@
 #include <stdint.h>
 
 #define RT_MAX_AXIS_CELLS 64                       // resolution clamp of Serial/grid.h:100
-#define RT_MAX_CELLS (64 * 64 * 64)
-#define RT_SCAN_CHUNK 1024                         // cells per scan block
-#define RT_MAX_SCAN_BLOCKS (RT_MAX_CELLS / RT_SCAN_CHUNK)
+#define RT_MAX_VOXELS (64 * 64 * 64)                // voxels of the largest grid
+// Cells. Every per-voxel table (counts, list starts, occupancy bits) is laid out for the grid with ONE LAYER OF BORDER CELLS
+// around it: cell (x + 1) + (n[0] + 2) * ((y + 1) + (n[1] + 2) * (z + 1)) for voxel (x, y, z). Border cells hold no triangle
+// and have their occupancy bit SET: a ray that leaves the grid stops at one like at an occupied voxel and is found to be
+// done there, so the walk loop carries no per-axis count of the voxels left (rt_kernels.hip, step_through_empty).
+#define RT_MAX_CELLS (66 * 66 * 66)
+#define RT_SCAN_CHUNK 1280                         // cells per scan block (a multiple of 256)
+#define RT_MAX_SCAN_BLOCKS ((RT_MAX_CELLS + RT_SCAN_CHUNK - 1) / RT_SCAN_CHUNK)      // at most 256: k_scan_apply sums them with one block
 #define RT_WORK_LIST_COUNTS 32                     // first work[] word of the per-list tile counts (128 bytes after the head)
 #define RT_COST_SUM_PARTS 32u                       // partial sums of the cost estimate (power of two)
 #define RT_COUNTER_WORDS 216                       // 24 frame counters, 32 work-list words (64 x u32), 32 partial sums of the cost estimate, 8 x 16 for the dequeue heads (a cache line each)
@@ -27,7 +32,7 @@ struct RtGrid {
     float width[3];
     float inv_width[3];
     int32_t n[3];
-    int32_t n_cells;
+    int32_t n_cells;        // cells of the bordered layout: (n[0] + 2) * (n[1] + 2) * (n[2] + 2)
     uint32_t n_refs;        // total (cell, triangle) references = cell_start[n_cells]
     uint32_t overflow;      // set when n_refs exceeds the capacity the scatter was given
     uint32_t pad[2];
@@ -75,7 +80,7 @@ struct RtSceneDev {
     uint32_t n_tris;
     const RtGrid* grid;
     const uint32_t* cell_start;   // n_cells + 1
-    const uint32_t* occupancy;    // 1 bit per cell
+    const uint32_t* occupancy;    // 1 bit per cell (border cells: set)
     const float4* tri_rec;        // 3 float4 per triangle, triangle order
     const float4* recs;           // cell-major voxel lists: 3 float4 per reference, or (indexed) one uint32 triangle index per reference
     uint32_t indexed;

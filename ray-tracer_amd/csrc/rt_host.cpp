@@ -904,7 +904,7 @@ extern "C" int rt_scene_get_grid(rt_scene* s, int32_t n[3], float lohi[6], float
         if (width) width[a] = g.width[a];
         if (inv_width) inv_width[a] = g.inv_width[a];
     }
-    if (n_cells) *n_cells = (uint32_t)g.n_cells;
+    if (n_cells) *n_cells = (uint32_t)(g.n[0] * g.n[1] * g.n[2]);      // voxels (the device tables have a layer of border cells around them)
     if (n_refs) *n_refs = g.n_refs;
     return RT_OK;
 }
@@ -924,7 +924,17 @@ extern "C" int rt_scene_get_csr(rt_scene* s, uint32_t* cell_start, uint32_t* cel
     }
     RtGrid g;
     HIP_TRY(hipMemcpy(&g, w.d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
-    if (cell_start) HIP_TRY(hipMemcpy(cell_start, w.cell_start.p, ((size_t)g.n_cells + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cell_start) {
+        // the device table is laid out with a layer of (empty) border cells around the grid: the voxels' entries, in voxel order
+        std::vector<uint32_t> bordered((size_t)g.n_cells + 1);
+        HIP_TRY(hipMemcpy(bordered.data(), w.cell_start.p, bordered.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const size_t row = (size_t)g.n[0] + 2, layer = row * ((size_t)g.n[1] + 2);
+        size_t c = 0;
+        for (int z = 0; z < g.n[2]; ++z)
+            for (int y = 0; y < g.n[1]; ++y)
+                for (int x = 0; x < g.n[0]; ++x) cell_start[c++] = bordered[(size_t)(x + 1) + row * (size_t)(y + 1) + layer * (size_t)(z + 1)];
+        cell_start[c] = bordered[(size_t)g.n_cells];
+    }
     if (cell_tris && g.n_refs) {
         DevBuf<uint32_t> tmp;
         int rc = tmp.ensure(g.n_refs);
@@ -1065,9 +1075,9 @@ static int render_frame(rt_scene* s, const rt_params* p, const FrameMem& m, int 
     f.count_work = counting ? 1 : 0;
     f.shading_mode = p->shading_mode;
     if (counting && p->shading_mode != RT_SHADE_SERIAL) return set_err(RT_ERR_INVALID, "the counting build of the render kernel exists for RT_SHADE_SERIAL only");
-    // A grid has at most RT_MAX_CELLS voxels: from two references per voxel on average it is crowded for certain, and the
+    // A grid has at most RT_MAX_VOXELS voxels: from two references per voxel on average it is crowded for certain, and the
     // trace kernel without the path for voxels of a few records is used.
-    f.own_path = (s->known_refs >= 2u * (uint32_t)RT_MAX_CELLS) ? 0 : 1;
+    f.own_path = (s->known_refs >= 2u * (uint32_t)RT_MAX_VOXELS) ? 0 : 1;
     if (s->own_path_override >= 0) f.own_path = s->own_path_override;
     // Frames in which most (run, ray) trips find a triangle (every ray of a tile on one flat patch: 60 hit trips per
     // streamed run on the generated plane, against 1 on a mesh seen from afar) go to the kernel variant that finishes a
@@ -1407,7 +1417,7 @@ extern "C" int rt_scene_stats_at(rt_scene* s, int32_t frames_back, rt_frame_stat
     HIP_TRY(hipMemcpy(&g, s->sets[s->cur].d_grid.p, sizeof(g), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(c, s->sets[s->cur].counters.p, sizeof(c), hipMemcpyDeviceToHost));
     for (int a = 0; a < 3; ++a) out->grid_n[a] = g.n[a];
-    out->n_cells = (uint32_t)g.n_cells;
+    out->n_cells = (uint32_t)(g.n[0] * g.n[1] * g.n[2]);
     out->n_refs = g.n_refs;
     out->n_triangles = s->tri_mesh.size();
     // rows of this part that lie inside the frame

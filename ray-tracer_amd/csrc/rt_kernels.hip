@@ -200,7 +200,7 @@ __device__ __forceinline__ void grid_setup(const RtBuildDev& b) {
         g->n[a] = nv;
         g->width[a] = delta[a] / (float)nv;
         g->inv_width[a] = (g->width[a] == 0.f) ? 0.f : 1.f / g->width[a];
-        cells *= nv;
+        cells *= nv + 2;                   // one layer of border cells around the grid (rt_device.h)
     }
     g->n_cells = cells;
 }
@@ -211,15 +211,15 @@ __global__ void k_grid_setup(RtBuildDev b) {
     if (threadIdx.x == 0 && blockIdx.x == 0) grid_setup(b);
 }
 
-// Voxel range of one triangle's bounding box, Serial/grid.h:121-131.
+// Voxel range of one triangle's bounding box, Serial/grid.h:121-131, as coordinates in the bordered cell layout (voxel + 1).
 __device__ __forceinline__ void tri_voxel_range(const RtBuildDev& b, const RtGrid& g, uint32_t i, int vmin[3], int vmax[3]) {
     const float2 p = b.tri_box[3ull * i], q = b.tri_box[3ull * i + 1], r = b.tri_box[3ull * i + 2];
     float lo[3] = {p.x, p.y, q.x};
     float hi[3] = {q.y, r.x, r.y};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        vmin[a] = pos_to_voxel(lo[a], g.lo[a], g.inv_width[a], g.n[a]);
-        vmax[a] = pos_to_voxel(hi[a], g.lo[a], g.inv_width[a], g.n[a]);
+        vmin[a] = pos_to_voxel(lo[a], g.lo[a], g.inv_width[a], g.n[a]) + 1;
+        vmax[a] = pos_to_voxel(hi[a], g.lo[a], g.inv_width[a], g.n[a]) + 1;
     }
 }
 
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) k_count(RtBuildDev b) {
     int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
     const RtGrid g = *b.grid;                  // same address in every lane; in flight together with the vertex loads
     if (valid) tri_voxel_range(b, g, i, vmin, vmax);
-    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int nx = g.n[0] + 2, nxy = nx * (g.n[1] + 2);      // row and layer of the bordered cell layout
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
     const int n_all = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
     // a triangle with a large voxel range (a ground quad under a detailed mesh: thousands of voxels) would keep its
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) k_count_wide(RtBuildDev b) {
     const RtGrid g = *b.grid;
     int vmin[3], vmax[3];
     tri_voxel_range(b, g, i, vmin, vmax);
-    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int nx = g.n[0] + 2, nxy = nx * (g.n[1] + 2);      // row and layer of the bordered cell layout
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1, exy = ex * ey;
     const int n = exy * (vmax[2] - vmin[2] + 1);
     for (int r = lane; r < n; r += 64) {
@@ -322,7 +322,7 @@ __global__ void k_scan_sums(RtBuildDev b) {
     uint32_t base = blockIdx.x * RT_SCAN_CHUNK;
     uint32_t s = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RT_SCAN_CHUNK / 256; ++j) {
         uint32_t c = base + j * 256 + threadIdx.x;
         s += (c < (uint32_t)n_cells) ? b.cell_count[c] : 0u;
     }
@@ -334,7 +334,7 @@ __global__ void k_scan_sums(RtBuildDev b) {
 }
 
 // SCAN part 2: exclusive prefix inside every chunk plus the total of the chunks before it; also the
-// occupancy bitmap (1 bit per cell) the render kernel uses to skip empty voxels.
+// occupancy bitmap (1 bit per cell, set for occupied voxels and for border cells) the render kernel walks by.
 __global__ void k_scan_apply(RtBuildDev b) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t wtot[4];
@@ -350,10 +350,14 @@ __global__ void k_scan_apply(RtBuildDev b) {
     if (lane == 0) red[wv] = pre;
     __syncthreads();
     uint32_t carry = red[0] + red[1] + red[2] + red[3];
-    for (int j = 0; j < 4; ++j) {
+    const uint32_t px = (uint32_t)b.grid->n[0] + 2u, py = (uint32_t)b.grid->n[1] + 2u, pz = (uint32_t)b.grid->n[2] + 2u;
+    for (int j = 0; j < RT_SCAN_CHUNK / 256; ++j) {
         uint32_t c = base + j * 256 + threadIdx.x;
         uint32_t v = (c < n_cells) ? b.cell_count[c] : 0u;
-        unsigned long long occ = __ballot(v != 0);
+        // the bit of a border cell is set (nothing is ever counted into one)
+        const uint32_t cz = c / (px * py), cr = c - cz * (px * py), cy = cr / px, cx = cr - cy * px;
+        const bool border = c < n_cells && (cx == 0u || cx == px - 1u || cy == 0u || cy == py - 1u || cz == 0u || cz == pz - 1u);
+        unsigned long long occ = __ballot(v != 0 || border);
         if (lane == 0 && (c < n_cells)) {
             b.occupancy[c >> 5] = (uint32_t)occ;
             b.occupancy[(c >> 5) + 1] = (uint32_t)(occ >> 32);
@@ -399,7 +403,7 @@ __global__ void __launch_bounds__(256) k_scatter(RtBuildDev b) {
     const uint32_t i = (valid && b.order) ? b.order[t] : t;
     int vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
     if (valid) tri_voxel_range(b, g, i, vmin, vmax);
-    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int nx = g.n[0] + 2, nxy = nx * (g.n[1] + 2);      // row and layer of the bordered cell layout
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
     const int n_all = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
     const bool big = n_all > RT_BIG_RANGE;              // as in k_count
@@ -462,7 +466,7 @@ __global__ void __launch_bounds__(256) k_scatter_emit(RtBuildDev b) {
             rec0 = r[0]; rec1 = r[1]; rec2 = r[2];
         }
     }
-    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int nx = g.n[0] + 2, nxy = nx * (g.n[1] + 2);      // row and layer of the bordered cell layout
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1;
     const int n_all = valid ? ex * ey * (vmax[2] - vmin[2] + 1) : 0;
     const bool big = n_all > RT_BIG_RANGE;              // as in k_count
@@ -526,7 +530,7 @@ __global__ void __launch_bounds__(256) k_scatter_emit_wide(RtBuildDev b) {
     const float4* rr = b.tri_rec + 3ull * i;
     float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
     if (!b.indexed) { rec0 = rr[0]; rec1 = rr[1]; rec2 = rr[2]; }
-    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int nx = g.n[0] + 2, nxy = nx * (g.n[1] + 2);      // row and layer of the bordered cell layout
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1, exy = ex * ey;
     const int n = exy * (vmax[2] - vmin[2] + 1);
     for (int r = lane; r < n; r += 64) {
@@ -555,7 +559,7 @@ __global__ void __launch_bounds__(256) k_scatter_wide(RtBuildDev b) {
     if (i >= b.n_tris) return;
     int vmin[3], vmax[3];
     tri_voxel_range(b, g, i, vmin, vmax);
-    const int nx = g.n[0], nxy = g.n[0] * g.n[1];
+    const int nx = g.n[0] + 2, nxy = nx * (g.n[1] + 2);      // row and layer of the bordered cell layout
     const int ex = vmax[0] - vmin[0] + 1, ey = vmax[1] - vmin[1] + 1, exy = ex * ey;
     const int n = exy * (vmax[2] - vmin[2] + 1);
     for (int r = lane; r < n; r += 64) {
@@ -953,7 +957,7 @@ hipError_t rt_launch_extract_cell_tris(const float4* recs, uint32_t* out, uint32
 
 #define RT_WAVES_PER_BLOCK 4
 #define RT_CULL_LANE_RUNS 12                        // voxels with more 64-record runs than this are culled run-parallel
-#define RT_MAX_BITMAP_WORDS (RT_MAX_CELLS / 32)
+#define RT_MAX_BITMAP_WORDS ((RT_MAX_CELLS + 31) / 32)
 
 struct GridU {               // grid description held in scalar registers
     float lo[3], hi[3], width[3], inv_width[3];
@@ -1179,10 +1183,12 @@ __device__ __forceinline__ void dda_axis(const GridU& g, int a, int stride, floa
 }
 
 __device__ __forceinline__ void dda_setup(Dda& w, const GridU& g, float ox, float oy, float oz, float dx, float dy, float dz, float rayT) {
-    w.cell = 0;
+    // cells of the bordered layout: voxel (0, 0, 0) is cell 1 + row + layer
+    const int row = g.n[0] + 2, layer = row * (g.n[1] + 2);
+    w.cell = 1 + row + layer;
     dda_axis(g, 0, 1, ox, dx, rayT, w.next0, w.delta0, w.left0, w.cstep0, w.cell);
-    dda_axis(g, 1, g.n[0], oy, dy, rayT, w.next1, w.delta1, w.left1, w.cstep1, w.cell);
-    dda_axis(g, 2, g.n[0] * g.n[1], oz, dz, rayT, w.next2, w.delta2, w.left2, w.cstep2, w.cell);
+    dda_axis(g, 1, row, oy, dy, rayT, w.next1, w.delta1, w.left1, w.cstep1, w.cell);
+    dda_axis(g, 2, layer, oz, dz, rayT, w.next2, w.delta2, w.left2, w.cstep2, w.cell);
 }
 
 // @phase step
@@ -1232,19 +1238,21 @@ __device__ __forceinline__ bool dda_advance(Dda& w, bool early_hit, float best_t
 #ifndef RT_STEPS_PER_ROUND
 #define RT_STEPS_PER_ROUND 8
 #endif
-// The empty-voxel loop of the walk for a whole wavefront, scheduled by hand: every lane in `moving` whose voxel is empty
-// takes dda_advance steps (same selections, same additions, so the same state to the bit) until it stands at an occupied
-// voxel, has taken RT_STEPS_PER_ROUND steps, or is done (leaves the grid, or has a hit nearer than `lim` where `no_early`
-// does not hold its bit); the lanes that are done come back as a mask. Why by hand: written as a loop over dda_advance the
-// compiler spends 33 scalar instructions per voxel on saving, narrowing and restoring the execution mask around the
-// loop's two exit conditions and the axis selects; here the three axes are updated under three execution masks (an
-// addition, a count-down and an index step each) and the loop keeps one mask of the lanes still stepping.
+// The empty-voxel loop of the walk for a whole wavefront, scheduled by hand: every lane in `moving` whose cell is empty
+// takes dda_advance steps (same selections, same additions, so the same crossings to the bit) until it stands at a cell
+// whose bit is set, has taken RT_STEPS_PER_ROUND steps, or has a hit nearer than `lim` where `no_early` does not hold its
+// bit; the lanes that stopped for a hit come back as a mask. There is no count of the voxels left along each axis: a ray
+// that leaves the grid steps into a border cell, whose bit is set (rt_device.h), and the caller finds it done there.
+// Why by hand: written as a loop over dda_advance the compiler spends 33 scalar instructions per voxel on saving, narrowing
+// and restoring the execution mask around the loop's two exit conditions and the axis selects; here the three axes are
+// updated under three execution masks (an addition and an index step each) and the loop keeps one mask of the lanes still
+// stepping: 15 vector and 15 scalar instructions per voxel.
 // A compare that writes scalar registers is followed by two other instructions before a vector instruction reads them.
 __device__ __forceinline__ unsigned long long step_through_empty(Dda& w, const uint32_t* bitmap, float lim, unsigned long long no_early,
                                                                  unsigned long long moving) {
     const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)bitmap;
-    unsigned long long done, saved, c01, go, tm, t0s_dummy;
-    uint32_t t0, t1, t2;
+    unsigned long long done, saved, c01, go, tm, ts;
+    uint32_t t0, t1;
     int cnt;
     asm volatile(
         "s_mov_b64 %[saved], exec\n\t"
@@ -1259,33 +1267,26 @@ __device__ __forceinline__ unsigned long long step_through_empty(Dda& w, const u
         "v_cndmask_b32_e64 %[t1], %[n1], %[n0], %[c01]\n\t"        // the nearer crossing of axes 0 and 1 (axis 1 on a tie)
         "ds_read_b32 %[t0], %[t0]\n\t"
         "v_cmp_lt_f32_e32 vcc, %[t1], %[n2]\n\t"                    // ... is nearer than that of axis 2 (axis 2 on a tie)
-        "v_cndmask_b32_e64 %[t2], %[l1], %[l0], %[c01]\n\t"
-        "s_nop 0\n\t"
-        "v_cndmask_b32_e32 %[t1], %[n2], %[t1], vcc\n\t"             // t1: crossing into the next voxel
-        "v_cndmask_b32_e32 %[t2], %[l2], %[t2], vcc\n\t"             // t2: steps left along the axis of that crossing
-        "v_cmp_nlt_f32_e64 %[go], %[lim], %[t1]\n\t"                // no hit nearer than the crossing ...
-        "v_cmp_ne_u32_e64 %[tm], 0, %[t2]\n\t"                      // ... and not in the last voxel of the axis
-        "s_or_b64 %[go], %[go], %[noearly]\n\t"
-        "s_and_b64 %[go], %[go], %[tm]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[t1], %[n2], %[t1], vcc\n\t"             // t1: crossing into the next cell
+        "v_cmp_nlt_f32_e64 %[go], %[lim], %[t1]\n\t"                // no hit nearer than the crossing
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_bfe_u32 %[t0], %[t0], %[cell], 1\n\t"                    // the voxel's bit (offset = the low five bits of the index)
-        "v_cmp_eq_u32_e64 %[tm], 0, %[t0]\n\t"                      // lanes at an empty voxel
-        "s_andn2_b64 %[t0s], %[tm], %[go]\n\t"                      // of them: done
+        "v_bfe_u32 %[t0], %[t0], %[cell], 1\n\t"                    // the cell's bit (offset = the low five bits of the index)
+        "s_or_b64 %[go], %[go], %[noearly]\n\t"
+        "v_cmp_eq_u32_e64 %[tm], 0, %[t0]\n\t"                      // lanes at an empty cell
+        "s_andn2_b64 %[ts], %[tm], %[go]\n\t"                       // of them: done
         "s_and_b64 %[go], %[tm], %[go]\n\t"                         //          stepping on
-        "s_or_b64 %[done], %[done], %[t0s]\n\t"
-        "s_and_b64 %[t0s], %[c01], vcc\n\t"                         // along axis 0
-        "s_and_b64 exec, %[t0s], %[go]\n\t"
+        "s_or_b64 %[done], %[done], %[ts]\n\t"
+        "s_and_b64 %[ts], %[c01], vcc\n\t"                          // along axis 0
+        "s_and_b64 exec, %[ts], %[go]\n\t"
         "v_add_f32_e32 %[n0], %[n0], %[d0]\n\t"
-        "v_add_u32_e32 %[l0], -1, %[l0]\n\t"
         "v_add_u32_e32 %[cell], %[cell], %[c0]\n\t"
-        "s_andn2_b64 %[t0s], vcc, %[c01]\n\t"                       // along axis 1
-        "s_and_b64 exec, %[t0s], %[go]\n\t"
+        "s_andn2_b64 %[ts], vcc, %[c01]\n\t"                        // along axis 1
+        "s_and_b64 exec, %[ts], %[go]\n\t"
         "v_add_f32_e32 %[n1], %[n1], %[d1]\n\t"
-        "v_add_u32_e32 %[l1], -1, %[l1]\n\t"
         "v_add_u32_e32 %[cell], %[cell], %[c1]\n\t"
         "s_andn2_b64 exec, %[go], vcc\n\t"                          // along axis 2
         "v_add_f32_e32 %[n2], %[n2], %[d2]\n\t"
-        "v_add_u32_e32 %[l2], -1, %[l2]\n\t"
         "v_add_u32_e32 %[cell], %[cell], %[c2]\n\t"
         "s_mov_b64 exec, %[go]\n\t"
         "s_cbranch_execz .Lstep_end%=\n\t"
@@ -1294,19 +1295,20 @@ __device__ __forceinline__ unsigned long long step_through_empty(Dda& w, const u
         "s_cbranch_scc1 .Lstep_loop%=\n"
         ".Lstep_end%=:\n\t"
         "s_mov_b64 exec, %[saved]"
-        : [cell] "+v"(w.cell), [n0] "+v"(w.next0), [n1] "+v"(w.next1), [n2] "+v"(w.next2), [l0] "+v"(w.left0), [l1] "+v"(w.left1), [l2] "+v"(w.left2),
-          [done] "=&s"(done), [saved] "=&s"(saved), [c01] "=&s"(c01), [go] "=&s"(go), [tm] "=&s"(tm), [t0s] "=&s"(t0s_dummy),
-          [cnt] "=&s"(cnt), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [cell] "+v"(w.cell), [n0] "+v"(w.next0), [n1] "+v"(w.next1), [n2] "+v"(w.next2),
+          [done] "=&s"(done), [saved] "=&s"(saved), [c01] "=&s"(c01), [go] "=&s"(go), [tm] "=&s"(tm), [ts] "=&s"(ts),
+          [cnt] "=&s"(cnt), [t0] "=&v"(t0), [t1] "=&v"(t1)
         : [d0] "v"(w.delta0), [d1] "v"(w.delta1), [d2] "v"(w.delta2), [c0] "v"(w.cstep0), [c1] "v"(w.cstep1), [c2] "v"(w.cstep2),
           [lim] "v"(lim), [base] "s"(base), [noearly] "s"(no_early), [moving] "s"(moving), [steps] "n"(RT_STEPS_PER_ROUND)
         : "vcc", "scc");
     return done;
 }
 
-// One dda_advance step for the lanes in `moving`, in the same form; returns the lanes that are done.
+// One dda_advance step for the lanes in `moving`, in the same form (a lane in the last voxel of an axis steps into the
+// border cell); returns the lanes that stopped for a hit instead.
 __device__ __forceinline__ unsigned long long step_once(Dda& w, float lim, unsigned long long no_early, unsigned long long moving) {
-    unsigned long long done, saved, c01, go, tm;
-    uint32_t t1, t2;
+    unsigned long long done, saved, c01, go, ts;
+    uint32_t t1;
     asm volatile(
         "s_mov_b64 %[saved], exec\n\t"
         "s_and_b64 exec, exec, %[moving]\n\t"
@@ -1314,33 +1316,27 @@ __device__ __forceinline__ unsigned long long step_once(Dda& w, float lim, unsig
         "s_mov_b64 %[done], exec\n\t"
         "s_nop 0\n\t"
         "v_cndmask_b32_e64 %[t1], %[n1], %[n0], %[c01]\n\t"
-        "v_cndmask_b32_e64 %[t2], %[l1], %[l0], %[c01]\n\t"
         "v_cmp_lt_f32_e32 vcc, %[t1], %[n2]\n\t"
         "s_nop 1\n\t"
         "v_cndmask_b32_e32 %[t1], %[n2], %[t1], vcc\n\t"
-        "v_cndmask_b32_e32 %[t2], %[l2], %[t2], vcc\n\t"
         "v_cmp_nlt_f32_e64 %[go], %[lim], %[t1]\n\t"
-        "v_cmp_ne_u32_e64 %[tm], 0, %[t2]\n\t"
         "s_or_b64 %[go], %[go], %[noearly]\n\t"
-        "s_and_b64 %[go], %[go], %[tm]\n\t"
+        "s_and_b64 %[go], %[go], %[done]\n\t"
         "s_andn2_b64 %[done], %[done], %[go]\n\t"
-        "s_and_b64 %[tm], %[c01], vcc\n\t"
-        "s_and_b64 exec, %[tm], %[go]\n\t"
+        "s_and_b64 %[ts], %[c01], vcc\n\t"
+        "s_and_b64 exec, %[ts], %[go]\n\t"
         "v_add_f32_e32 %[n0], %[n0], %[d0]\n\t"
-        "v_add_u32_e32 %[l0], -1, %[l0]\n\t"
         "v_add_u32_e32 %[cell], %[cell], %[c0]\n\t"
-        "s_andn2_b64 %[tm], vcc, %[c01]\n\t"
-        "s_and_b64 exec, %[tm], %[go]\n\t"
+        "s_andn2_b64 %[ts], vcc, %[c01]\n\t"
+        "s_and_b64 exec, %[ts], %[go]\n\t"
         "v_add_f32_e32 %[n1], %[n1], %[d1]\n\t"
-        "v_add_u32_e32 %[l1], -1, %[l1]\n\t"
         "v_add_u32_e32 %[cell], %[cell], %[c1]\n\t"
         "s_andn2_b64 exec, %[go], vcc\n\t"
         "v_add_f32_e32 %[n2], %[n2], %[d2]\n\t"
-        "v_add_u32_e32 %[l2], -1, %[l2]\n\t"
         "v_add_u32_e32 %[cell], %[cell], %[c2]\n\t"
         "s_mov_b64 exec, %[saved]"
-        : [cell] "+v"(w.cell), [n0] "+v"(w.next0), [n1] "+v"(w.next1), [n2] "+v"(w.next2), [l0] "+v"(w.left0), [l1] "+v"(w.left1), [l2] "+v"(w.left2),
-          [done] "=&s"(done), [saved] "=&s"(saved), [c01] "=&s"(c01), [go] "=&s"(go), [tm] "=&s"(tm), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [cell] "+v"(w.cell), [n0] "+v"(w.next0), [n1] "+v"(w.next1), [n2] "+v"(w.next2),
+          [done] "=&s"(done), [saved] "=&s"(saved), [c01] "=&s"(c01), [go] "=&s"(go), [ts] "=&s"(ts), [t1] "=&v"(t1)
         : [d0] "v"(w.delta0), [d1] "v"(w.delta1), [d2] "v"(w.delta2), [c0] "v"(w.cstep0), [c1] "v"(w.cstep1), [c2] "v"(w.cstep2),
           [lim] "v"(lim), [noearly] "s"(no_early), [moving] "s"(moving)
         : "vcc", "scc");
@@ -1373,7 +1369,7 @@ __device__ __forceinline__ void bitmap_to_lds(uint32_t* bitmap, const uint32_t* 
 // frame does not end on a single wavefront.
 // work[] words: [0] listed tiles, [RT_WORK_HEADS + RT_WORK_HEAD_STRIDE * q] dequeue head q; tiles per queue list from RT_WORK_LIST_COUNTS on, in another cache
 // line than the dequeue head: every dequeue reads them, and loads from the line all wavefronts hit with atomics queue up.
-#define RT_EST_CELLS 28          // occupied voxels noted per estimate ray (LDS: 4 bytes x 256 lanes each)
+#define RT_EST_CELLS 12          // occupied voxels noted per estimate ray (LDS: 4 bytes x 256 lanes each)
 
 // Walks one ray through the grid. The walk itself only touches LDS: the occupied voxels are noted in a per-lane list
 // (the first RT_EST_CELLS of them) and their triangle counts are then fetched with independent loads, several in
@@ -1522,7 +1518,7 @@ __global__ void __launch_bounds__(256) k_bucket(uint32_t* work, const uint32_t* 
             // adapt == 2: other frames are in flight beside this one and fill the GPU while its last units run, so the
             // largest units pay from fewer tiles per wavefront on
             uint32_t up = (2u * n >= 5u * (uint32_t)n_waves ? 1u : 0u) + (n >= (adapt == 2 ? 8u : 10u) * (uint32_t)n_waves ? 1u : 0u);
-            if (threadIdx.x < 8 && !(grid->n_refs < 2u * grid->n_cells)) up = up > 0u ? up - 1u : 0u;
+            if (threadIdx.x < 8 && !(grid->n_refs < 2u * (uint32_t)(grid->n[0] * grid->n[1] * grid->n[2]))) up = up > 0u ? up - 1u : 0u;
             sh = sh > up ? sh - up : 0u;
         }
         work[RT_WORK_LIST_COUNTS + RT_QUEUE_LISTS + threadIdx.x] = sh;
@@ -1978,11 +1974,14 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
             alive = alive && !__builtin_amdgcn_inverse_ballot_w64(done);
         }
         if (!__ballot(alive)) break;
-        const bool at_voxel = alive && ((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u);
-        first = !at_voxel;                               // a ray still under way has not looked at its voxel yet
-        unsigned long long un = __ballot(at_voxel);
+        bool at_voxel = alive && ((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u);
         uint32_t cbeg = 0, cend = 0;
         if (at_voxel) { cbeg = s.cell_start[w.cell]; cend = s.cell_start[w.cell + 1]; }
+        // A cell whose bit is set and that holds nothing is a border cell: the ray has left the grid (the loop the compiler
+        // makes of dda_advance never gets there, it counts the voxels down).
+        if (!COUNT && RT_STEP_BY_HAND && at_voxel && cend == cbeg) { alive = false; at_voxel = false; }
+        first = !at_voxel;                               // a ray still under way has not looked at its voxel yet
+        unsigned long long un = __ballot(at_voxel);
         const long long t1 = COUNT ? (long long)__builtin_amdgcn_s_memtime() : 0;
         if (COUNT) { wc.rounds += 1; wc.cyc_step += (uint32_t)(t1 - t0); if (alive) wc.tests += cend - cbeg; }
         // most rounds of a unit only move a few rays on through empty space: nothing to cull or to test
