@@ -1933,7 +1933,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off));
     }
     const double ddx = dx, ddy = dy, ddz = dz;
-    const float ifx = (float)(1.0 / ddx), ify = (float)(1.0 / ddy), ifz = (float)(1.0 / ddz);     // for the per-run box test
+    // reciprocals for the per-run box test (1 ulp: the test's margins allow for it; a zero component gives inf like a division)
+    const float ifx = __builtin_amdgcn_rcpf(dx), ify = __builtin_amdgcn_rcpf(dy), ifz = __builtin_amdgcn_rcpf(dz);
     // @phase step
     for (;;) {
         // ---- STEP: on to the next occupied voxel
@@ -2011,7 +2012,8 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // triangle of the run is always kept; fminf/fmaxf drop NaNs (0 * inf, inf - inf), which keeps the run as well, and
         // so does a line parallel to the slab whose origin lies inside it (-inf .. +inf).
         // A face at q is crossed at (q - o) / d, evaluated as fma(q, 1/d, -(o * 1/d)) with o * 1/d made once per ray:
-        // both forms round within 2 * 2^-24 * (|q| + |o|) / |d| of the exact value, a thirtieth of what mg moves the face by.
+        // with 1/d good to one unit in the last place this rounds within 2^-22 * (|q| + |o|) / |d| of the exact value, a fifteenth of
+        // what mg moves the face by.
         // roa = |o.x| + |o.y| + |o.z|; (rpx, rpy, rpz) = o * (1/d) per component.
         auto box_hit = [](const float4 q0, const float4 q1, const float4 q2, float rox, float roy, float roz, float roa, float rpx, float rpy, float rpz,
                           float rix, float riy, float riz, float rdx, float rdy, float rdz) -> bool {
