@@ -184,6 +184,25 @@ def test_work_counters_match_oracle_early_exit(rt, O, plane10, name):
         assert got[k] == want[k], (k, got[k], want[k])
 
 
+@pytest.mark.parametrize("mode", ["early", "full"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_both_forms_of_the_walk_loop_give_the_golden_image(rt, plane10, name, mode):
+    """The product kernels step through empty voxels with a hand-scheduled loop that has no count of the voxels left along
+    an axis (a ray that leaves the grid stops at a border cell of the grid tables); the counting kernels keep the loop over
+    dda_advance, which counts the voxels down and never steps into a border cell. Same frame from both, bit for bit,
+    also with the camera inside the grid and with rays leaving through every face."""
+    s, W, H, cam = _scene(rt, name, plane10)
+    p = rt.default_params(W, H, walk_mode=rt.RT_WALK_FULL if mode == "full" else rt.RT_WALK_EARLY, **cam_kwargs(cam))
+    g_ids, g_rgb = golden(name)
+    rgb, _, ids = s.render(p)
+    s.set_counting(True)
+    rgb_c, _, ids_c = s.render(p)
+    s.set_counting(False)
+    assert np.array_equal(ids, ids_c) and np.array_equal(bits(rgb), bits(rgb_c))
+    check_image(rgb, ids, g_rgb, g_ids)
+    s.close()
+
+
 @pytest.mark.parametrize("shifts,sched", [
     ("0000000000000000", None),          # every tile as one 64-ray unit
     ("4444444444444444", None),          # every tile cut into sixteen 4-ray units
