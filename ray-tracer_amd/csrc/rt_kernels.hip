@@ -1594,6 +1594,10 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);      // row_bcast:31
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// Bit i of a wavefront-uniform 64-bit mask cleared or set in one scalar instruction (`m &= m - 1` is three, `m |= 1ull << i`
+// two); the loops over the set bits of a lane mask below run millions of times per frame.
+__device__ __forceinline__ void mask_clear_bit(unsigned long long& m, int i) { asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(i)); }
+__device__ __forceinline__ void mask_set_bit(unsigned long long& m, int i) { asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(i)); }
 __device__ __forceinline__ double bcast_f64(double v, int src_lane) {
     const long long b = __double_as_longlong(v);
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b, src_lane);
@@ -2106,7 +2110,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 unsigned long long lm = mem, u0 = 0;
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
-                    lm &= lm - 1;
+                    mask_clear_bit(lm, i);
                     // with a shared origin everything of the test that depends on the origin alone is the same for all
                     // rays and leaves this loop
                     const float rox = SHARED_ORIGIN ? bcast_f32(ox, 0) : bcast_f32(ox, i), roy = SHARED_ORIGIN ? bcast_f32(oy, 0) : bcast_f32(oy, i),
@@ -2227,7 +2231,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 if (srest) {
                     // straight to the next run that some ray needs
                     k = (uint32_t)__ffsll((long long)srest) - 1u;
-                    srest &= srest - 1ull;
+                    mask_clear_bit(srest, (int)k);
                     rays &= __ballot((need0 >> k) & 1ull);
                 } else if (sextra < sextra_end) {
                     k = sextra++;                               // runs from 64 on (voxels of more than 4096 records): every ray
@@ -2283,14 +2287,14 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 unsigned long long todo = 0ull, rest = lm;
                 while (rest) {
                     const int i = __ffsll((long long)rest) - 1;
-                    rest &= rest - 1;
+                    mask_clear_bit(rest, i);
                     const int j = rest ? __ffsll((long long)rest) - 1 : i;
-                    rest &= rest - 1;
+                    mask_clear_bit(rest, j);
                     const rt_f2 rx = {bcast_f32(dx, i), bcast_f32(dx, j)}, ry = {bcast_f32(dy, i), bcast_f32(dy, j)}, rz = {bcast_f32(dz, i), bcast_f32(dz, j)};
                     unsigned long long ki, kj;
                     prefilter_pair(pf, rx, ry, rz, ki, kj);
-                    if (ki & have_m) todo |= 1ull << i;
-                    if (kj & have_m) todo |= 1ull << j;
+                    if (ki & have_m) mask_set_bit(todo, i);
+                    if (kj & have_m) mask_set_bit(todo, j);
                 }
                 if (COUNT) wc.loops[RT_LOOP_FILTER_KEPT] += (uint32_t)__popcll(todo);
                 lm = todo;
@@ -2300,15 +2304,15 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 unsigned long long todo = 0ull, rest = lm;
                 while (rest) {
                     const int i = __ffsll((long long)rest) - 1;
-                    rest &= rest - 1;
+                    mask_clear_bit(rest, i);
                     const int j = rest ? __ffsll((long long)rest) - 1 : i;
-                    rest &= rest - 1;
+                    mask_clear_bit(rest, j);
                     const rt_f2 px = {bcast_f32(ox, i), bcast_f32(ox, j)}, py = {bcast_f32(oy, i), bcast_f32(oy, j)}, pz = {bcast_f32(oz, i), bcast_f32(oz, j)};
                     const rt_f2 rx = {bcast_f32(dx, i), bcast_f32(dx, j)}, ry = {bcast_f32(dy, i), bcast_f32(dy, j)}, rz = {bcast_f32(dz, i), bcast_f32(dz, j)};
                     unsigned long long ki, kj;
                     prefilter_pair_own(pf, px, py, pz, rx, ry, rz, ki, kj);
-                    if (ki & have_m) todo |= 1ull << i;
-                    if (kj & have_m) todo |= 1ull << j;
+                    if (ki & have_m) mask_set_bit(todo, i);
+                    if (kj & have_m) mask_set_bit(todo, j);
                 }
                 if (COUNT) wc.loops[RT_LOOP_FILTER_KEPT] += (uint32_t)__popcll(todo);
                 lm = todo;
@@ -2331,7 +2335,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 for (;;) {
                 while (lm) {
                     const int i = __ffsll((long long)lm) - 1;
-                    lm &= lm - 1;
+                    mask_clear_bit(lm, i);
                     const double rdx = (double)bcast_f32(dx, i), rdy = (double)bcast_f32(dy, i), rdz = (double)bcast_f32(dz, i);   // widening is exact
                     if (!SHARED_ORIGIN) {
                         const float rox = bcast_f32(ox, i), roy = bcast_f32(oy, i), roz = bcast_f32(oz, i);
@@ -2402,7 +2406,7 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                             // the passing triangles go into the ray's summary of this voxel visit (any order)
                             while (pm) {
                                 const int pl = __ffsll((long long)pm) - 1;
-                                pm &= pm - 1;
+                                mask_clear_bit(pm, pl);
                                 const double t_p = bcast_f64(tt, pl);
                                 const int id_p = __builtin_amdgcn_readlane((int)t.id, pl);
                                 if (RULE == 0) {
