@@ -1304,6 +1304,54 @@ __device__ __forceinline__ unsigned long long step_through_empty(Dda& w, const u
     return done;
 }
 
+// The same loop for the case that no moving lane has a hit yet (most rounds: a ray that has one stops within a step or two,
+// and a shadow ray stops with its first): nothing can end a lane's walk but a set bit, so the crossing itself is not needed,
+// only its axis. 13 vector instructions per voxel.
+__device__ __forceinline__ void step_through_empty_no_hit(Dda& w, const uint32_t* bitmap, unsigned long long moving) {
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)bitmap;
+    unsigned long long saved, c01, go, ts;
+    uint32_t t0, t1;
+    int cnt;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_and_b64 exec, exec, %[moving]\n\t"
+        "s_movk_i32 %[cnt], %[steps]\n\t"
+        "s_cbranch_execz .Lstepn_end%=\n"
+        ".Lstepn_loop%=:\n\t"
+        "v_cmp_lt_f32_e64 %[c01], %[n0], %[n1]\n\t"
+        "v_lshrrev_b32_e32 %[t0], 5, %[cell]\n\t"
+        "v_lshl_add_u32 %[t0], %[t0], 2, %[base]\n\t"
+        "v_cndmask_b32_e64 %[t1], %[n1], %[n0], %[c01]\n\t"        // the nearer crossing of axes 0 and 1 (axis 1 on a tie)
+        "ds_read_b32 %[t0], %[t0]\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[t1], %[n2]\n\t"                    // ... is nearer than that of axis 2 (axis 2 on a tie)
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[t0], %[t0], %[cell], 1\n\t"
+        "v_cmp_eq_u32_e64 %[go], 0, %[t0]\n\t"                      // lanes at an empty cell step on
+        "s_and_b64 %[ts], %[c01], vcc\n\t"                          // along axis 0
+        "s_and_b64 exec, %[ts], %[go]\n\t"
+        "v_add_f32_e32 %[n0], %[n0], %[d0]\n\t"
+        "v_add_u32_e32 %[cell], %[cell], %[c0]\n\t"
+        "s_andn2_b64 %[ts], vcc, %[c01]\n\t"                        // along axis 1
+        "s_and_b64 exec, %[ts], %[go]\n\t"
+        "v_add_f32_e32 %[n1], %[n1], %[d1]\n\t"
+        "v_add_u32_e32 %[cell], %[cell], %[c1]\n\t"
+        "s_andn2_b64 exec, %[go], vcc\n\t"                          // along axis 2
+        "v_add_f32_e32 %[n2], %[n2], %[d2]\n\t"
+        "v_add_u32_e32 %[cell], %[cell], %[c2]\n\t"
+        "s_mov_b64 exec, %[go]\n\t"
+        "s_cbranch_execz .Lstepn_end%=\n\t"
+        "s_add_i32 %[cnt], %[cnt], -1\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 .Lstepn_loop%=\n"
+        ".Lstepn_end%=:\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [cell] "+v"(w.cell), [n0] "+v"(w.next0), [n1] "+v"(w.next1), [n2] "+v"(w.next2),
+          [saved] "=&s"(saved), [c01] "=&s"(c01), [go] "=&s"(go), [ts] "=&s"(ts), [cnt] "=&s"(cnt), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [d0] "v"(w.delta0), [d1] "v"(w.delta1), [d2] "v"(w.delta2), [c0] "v"(w.cstep0), [c1] "v"(w.cstep1), [c2] "v"(w.cstep2),
+          [base] "s"(base), [moving] "s"(moving), [steps] "n"(RT_STEPS_PER_ROUND)
+        : "vcc", "scc");
+}
+
 // One dda_advance step for the lanes in `moving`, in the same form (a lane in the last voxel of an axis steps into the
 // border cell); returns the lanes that stopped for a hit instead.
 __device__ __forceinline__ unsigned long long step_once(Dda& w, float lim, unsigned long long no_early, unsigned long long moving) {
@@ -1975,8 +2023,9 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 --steps_left;
             }
         } else {
-            const unsigned long long done = step_through_empty(w, bitmap, lim, no_early, __ballot(alive));
-            alive = alive && !__builtin_amdgcn_inverse_ballot_w64(done);
+            const unsigned long long moving = __ballot(alive);
+            if ((moving & ~no_early) == 0ull) step_through_empty_no_hit(w, bitmap, moving);
+            else alive = alive && !__builtin_amdgcn_inverse_ballot_w64(step_through_empty(w, bitmap, lim, no_early, moving));
         }
         if (!__ballot(alive)) break;
         bool at_voxel = alive && ((bitmap[w.cell >> 5] >> (w.cell & 31)) & 1u);
@@ -2274,9 +2323,10 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // @phase item
         auto process = [&](const Item& cur, const TriRec& t) {
             const uint32_t base = cur.base, e = cur.e;
-            const bool have = base + lane >= cur.b && base + lane < e;
+            const bool have = base + lane - cur.b < e - cur.b;           // cur.b <= base + lane < e in one unsigned compare (b <= e)
             const unsigned long long have_m = __ballot(have);
-            unsigned long long lm = cur.rays & __ballot(alive);          // rays that were hit meanwhile (shadow query) drop out
+            unsigned long long lm = cur.rays;
+            if (ANY_HIT) lm &= __ballot(alive);                          // rays that were hit meanwhile (shadow query) drop out
             if (COUNT) { wc.lanes += (uint32_t)__popcll(have_m) * (uint32_t)__popcll(lm); wc.items += 1; wc.trips += (uint32_t)__popcll(lm); }
             wc.fb_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc.fb_items + 1u));      // a scalar register, not one per lane
             if (COUNT) { wc.loops[RT_LOOP_ITEMS] += 1; wc.loops[RT_LOOP_TRIPS] += (uint32_t)__popcll(lm); if (lm) wc.loops[RT_LOOP_ITEMS_WITH_RAYS] += 1; }
