@@ -233,10 +233,11 @@ __device__ __forceinline__ void lane_groups(bool act, int c, int lane, int& head
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     head = lane; rank = 0; size = 1;
     unsigned long long rem = __ballot(act);
+    const int key = act ? c : -1;              // voxels are numbered from 0: a lane without one matches nobody (one compare per trip)
     for (int trip = 0; trip < RT_GROUP_TRIPS && rem; ++trip) {
         const int l = __ffsll((long long)rem) - 1;
-        const int c0 = __builtin_amdgcn_readlane(c, l);
-        const bool mine = act && c == c0;
+        const int c0 = __builtin_amdgcn_readlane(key, l);
+        const bool mine = key == c0;
         const unsigned long long m = __ballot(mine);
         if (mine) { head = l; rank = (uint32_t)__popcll(m & lt_mask); size = (uint32_t)__popcll(m); }
         rem &= ~m;
