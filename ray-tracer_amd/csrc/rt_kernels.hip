@@ -1883,6 +1883,10 @@ __device__ __forceinline__ void prefilter_pair_own(const PreFilterOwn& f, rt_f2 
 }
 
 // @phase other
+// primary rays resolve their single-candidate hit trips together at the end of the round (wave_walk); 0: on the spot
+#ifndef RT_ROUND_DEFER
+#define RT_ROUND_DEFER 1
+#endif
 // kernel variant DEFER: runs tested by at least this many rays resolve single-candidate trips together after the ray loop
 #ifndef RT_DEFER_MIN_RAYS
 #define RT_DEFER_MIN_RAYS 16
@@ -2322,6 +2326,14 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
         // without a next item loads the item it has again -- because loads behind a branch make the compiler merge the
         // two slots into one and wait for all outstanding loads before each test.
         // @phase item
+        // Hit trips put off to the end of the round (primary rays): a trip that leaves ONE candidate triangle only notes its
+        // index in the ray's lane; when the round's items are through, all rays with a note fetch their triangle's record and
+        // go through the determinants, the divisions and the exact test together, lane = ray, instead of one busy lane at a
+        // time in 64 (same expressions on the same values: same quotients to the bit). A ray that already holds a note, or
+        // finds several candidates in a run, resolves on the spot as before.
+        constexpr bool ROUND_DEFER = RT_ROUND_DEFER && SHARED_ORIGIN && !ANY_HIT && RULE == 0 && !DEFER && !COUNT;
+        int note_id = -1;
+        unsigned long long noted_m = 0ull;
         auto process = [&](const Item& cur, const TriRec& t) {
             const uint32_t base = cur.base, e = cur.e;
             const bool have = base + lane - cur.b < e - cur.b;           // cur.b <= base + lane < e in one unsigned compare (b <= e)
@@ -2414,7 +2426,11 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                     double tt = 0.0;
                     if (cand) wc.fb_hits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc.fb_hits + 1u));
                     if (COUNT && cand) wc.loops[RT_LOOP_TRIPS_CAND] += 1;
-                    if (DEFER && !at_once && (cand & (cand - 1ull)) == 0ull) {
+                    if (ROUND_DEFER && cand && (cand & (cand - 1ull)) == 0ull && !((noted_m >> i) & 1ull)) {
+                        const int id_c = __builtin_amdgcn_readlane((int)t.id, __ffsll((long long)cand) - 1);
+                        if (lane == i) note_id = id_c;
+                        mask_set_bit(noted_m, i);
+                    } else if (DEFER && !at_once && (cand & (cand - 1ull)) == 0ull) {
                         if (cand && lane == i) dc = __ffsll((long long)cand) - 1;
                     } else if (cand) {
                         // @phase resolve
@@ -2628,6 +2644,37 @@ __device__ __forceinline__ bool wave_walk(const RtSceneDev& s, const uint32_t* b
                 if (!hA) break;
                 hC = gen(itC);
                 load_item(itC, c0, c1, c2);
+            }
+        }
+        // @phase resolve
+        if (ROUND_DEFER && noted_m) {
+            const bool has = note_id >= 0;
+            float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+            if (has) { const float4* r = s.tri_rec + 3ull * (uint32_t)note_id; r0 = r[0]; r1 = r[1]; r2 = r[2]; }
+            const TriRec c = unpack_rec(r0, r1, r2);
+            const double rdx = dx, rdy = dy, rdz = dz;                               // widening is exact
+            const double c_sx = c.v0x - ox, c_sy = c.v0y - oy, c_sz = c.v0z - oz;       // float subtractions, then widened
+            const double q_e2s = minor_f32(c.e2y, c_sz, c_sy, c.e2z);
+            const double q_e1s = minor_f32(c.e1y, c_sz, c_sy, c.e1z);
+            const double q_e2d = minor_f32(c.e2y, rdz, rdy, c.e2z);
+            const double q_e1d = minor_f32(c.e1y, rdz, rdy, c.e1z);
+            const double q_sd = minor_f32(c_sy, rdz, rdy, c_sz);
+            const double A = c.e1x * q_e2d - c.e2x * q_e1d + rdx * c.m12;
+            const double bnum = c_sx * q_e2d - c.e2x * q_sd - rdx * q_e2s;
+            const double gnum = c.e1x * q_sd - c_sx * q_e1d + rdx * q_e1s;
+            const double tnum = c.e1x * q_e2s - c.e2x * q_e1s + c_sx * c.m12;
+            const uint32_t ea = exponent_field(A), eb = exponent_field(bnum), eg = exponent_field(gnum), et = exponent_field(tnum);
+            const uint32_t e_lo = min(min(ea, eb), min(eg, et)), e_hi = max(max(ea, eb), max(eg, et));
+            double beta, gamma, tq;
+            if ((noted_m & ~(__builtin_amdgcn_uicmp(e_lo, RT_DIV_EXP_LO, 35) & __builtin_amdgcn_uicmp(e_hi, RT_DIV_EXP_HI, 37))) == 0ull) {
+                const double rcp_a = div_rcp(A);
+                beta = div_with_rcp(bnum, A, rcp_a); gamma = div_with_rcp(gnum, A, rcp_a); tq = div_with_rcp(tnum, A, rcp_a);
+            } else {
+                beta = bnum / A; gamma = gnum / A; tq = tnum / A;
+            }
+            if (has && beta > 0.0 && gamma > 0.0 && beta + gamma < 1.0) {
+                hit = true;
+                if (!use_eps || tq > (double)eps) vb_add(vb, tq, note_id);
             }
         }
         // @phase apply
